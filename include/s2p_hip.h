@@ -1,0 +1,177 @@
+/* libs2p_hip.so -- C ABI of the MI355X (gfx950) S2P hot path.
+ *
+ * Drop-in boundary.  The reference checkout ships NO native code
+ * and NO generator source, so "the reference interface each entry
+ * replaces" is the PyTorch op the SPADE-lineage generator/discriminator would call from
+ * Python (README.md:72-75 names the lineage; README.md:33,59 name the CLI that reaches
+ * them).  Each entry point below cites that torch op; INTEGRATION.md shows the ctypes
+ * stub a maintainer adds.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is DEVICE memory owned by the caller
+ *     (the library never allocates, frees or retains device memory);
+ *   - every launch goes to the `stream` argument (a hipStream_t passed as void*), no
+ *     implicit synchronisation, safe under hipGraph capture;
+ *   - return 0 on success, negative on error; s2p_last_error() gives the message
+ *     (thread-local); no C++ exception crosses the ABI;
+ *   - activations are NHWC ("channels-last") in `dtype` (S2P_F32 or S2P_BF16); weights
+ *     are "packed" [group][Cout][tap][Cin_pad] in the same dtype (s2p_pack_weights);
+ *     master weights / gradients / optimizer state are fp32.
+ */
+#ifndef S2P_HIP_H
+#define S2P_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S2P_VERSION 100
+
+enum { S2P_F32 = 0, S2P_BF16 = 1 };
+enum { S2P_ACT_NONE = 0, S2P_ACT_RELU = 1, S2P_ACT_LRELU = 2, S2P_ACT_TANH = 3 };
+/* epilogue modes of the conv family */
+enum { S2P_EPI_STORE = 0,       /* y = act(conv + bias)                                   */
+       S2P_EPI_ADD = 1,         /* y = act(conv + bias) + aux          (residual add)     */
+       S2P_EPI_MUL_ACTGRAD = 2  /* y = conv * act'(aux)  (fused backward of the producer's
+                                   ReLU / LeakyReLU; aux = that producer's OUTPUT)        */ };
+
+/* One 2-D convolution problem, forward orientation.  torch equivalents:
+ *   transposed == 0 : F.conv2d(x, w, b, stride, padding)            (pad mode zeros/reflect)
+ *   transposed == 1 : F.conv_transpose2d(x, w, None, stride, padding, output_padding)
+ * x : [N, H, W, x_pitch>=groups*Cin]   y : [N, Ho, Wo, y_pitch>=groups*Cout]
+ * Cin must be a multiple of 16/sizeof(dtype) elements (pad thin inputs with zeros). */
+typedef struct {
+  int32_t dtype;
+  int32_t N, H, W, Cin, x_pitch;
+  int32_t Ho, Wo, Cout, y_pitch;
+  int32_t KH, KW, stride, pad;
+  int32_t transposed;
+  int32_t reflect;
+  int32_t groups;       /* >=1: batched independent convs; group g reads channels
+                           [g*x_gstride, +Cin) and writes [g*y_gstride, +Cout)          */
+  int32_t x_gstride, y_gstride;
+} s2p_conv_desc;
+
+int s2p_version(void);
+const char* s2p_last_error(void);
+
+/* ---- conv family (replaces torch.nn.functional.conv2d / conv_transpose2d and their
+ *      autograd backward: cudnn_convolution_backward_input / _weight) ---------------- */
+/* w_fwd : packed [groups][Cout][KH*KW][Cin]      (for transposed==1 too)               */
+int s2p_conv2d_fwd(const s2p_conv_desc* d, const void* x, const void* w_fwd, const float* bias,
+                   const void* aux, void* y, int act, float slope, int epi, void* stream);
+/* dx = d(loss)/dx.  w_bwd : packed [groups][Cin][KH*KW][Cout_pad] (the transpose of w_fwd).
+ * dy has pitch y_pitch and channel count Cout (must itself satisfy the chunk multiple).
+ * epi / aux as above (aux has the layout of dx); with S2P_EPI_MUL_ACTGRAD the result is
+ * multiplied by aux_act'(aux) (aux = OUTPUT of the activation that produced x).
+ * Reflect-padded convs: dx is produced on the PADDED grid [N,H+2p,W+2p,x_pitch]; fold it
+ * with s2p_reflect_pad_bwd.                                                             */
+int s2p_conv2d_dgrad(const s2p_conv_desc* d, const void* dy, const void* w_bwd,
+                     const void* aux, void* dx, int epi, int aux_act, float slope, void* stream);
+/* dw (fp32) [groups][Cout][KH*KW][Cin_real] for transposed==0,
+ *           [groups][Cin][KH*KW][Cout_real] for transposed==1  (= channels-last physical
+ * layout of the torch parameter).  dw is ACCUMULATED into (caller zeroes it);
+ * dw_gstride = elements between groups.  cin_real/cout_real: un-padded channel counts.  */
+int s2p_conv2d_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw,
+                     int cin_real, int cout_real, int64_t dw_gstride, int splitk, void* stream);
+/* adjoint of F.pad(mode='reflect'): dx[N,H,W,C] = fold(dxp[N,H+2p,W+2p,C])              */
+int s2p_reflect_pad_bwd(int dtype, const void* dxp, int N, int H, int W, int C, int pad, void* dx,
+                        void* stream);
+/* db[c] += sum over pixels of dy[p][c]  (bias gradient; fp32 accumulate into db)        */
+int s2p_channel_sum(int dtype, const void* dy, int64_t pixels, int C, int pitch, float* db,
+                    void* stream);
+
+/* ---- instance norm + MAT/SPADE modulation (replaces F.instance_norm + the elementwise
+ *      `normalized * (1 + gamma) + beta` + activation of the SPADE-lineage norm) -------- */
+/* stats[n][c] += {sum x, sum x^2} over HW (raw moments; caller zeroes stats first;
+ * consumers derive mean and rstd = rsqrt(biased var + eps))                             */
+int s2p_in_stats(int dtype, const void* x, int N, int HW, int C, int pitch, float eps,
+                 float* stats, void* stream);
+/* y = act(xhat*(1+g_img+g_st) + (b_img+b_st)).  gb_img: [N,HW,gb_pitch] with gamma at
+ * channel offset 0 and beta at offset C (NULL -> 0); gb_st: fp32 [N][gb_st_pitch], gamma at
+ * [0,C) beta at [C,2C) (NULL -> 0).                                                     */
+int s2p_in_apply_fwd(int dtype, const void* x, int N, int HW, int C, int pitch,
+                     const float* stats, const void* gb_img, int gb_pitch,
+                     const float* gb_st, int gb_st_pitch, int act, float slope, float eps,
+                     void* y, int y_pitch, void* stream);
+/* backward, given da = dL/dy (post-activation).  sums[n][c] = {S1,S2,dgamma_st,dbeta_st}
+ * must be zeroed by the caller before s2p_in_bwd_reduce.                                */
+int s2p_in_bwd_reduce(int dtype, const void* da, int da_pitch, const void* x, int N, int HW, int C,
+                      int pitch, const float* stats, const void* gb_img, int gb_pitch,
+                      const float* gb_st, int gb_st_pitch, int act, float slope, float eps,
+                      float* sums, void* stream);
+int s2p_in_bwd_apply(int dtype, const void* da, int da_pitch, const void* x, int N, int HW, int C,
+                     int pitch, const float* stats, const void* gb_img, int gb_pitch,
+                     const float* gb_st, int gb_st_pitch, int act, float slope, float eps,
+                     const float* sums, void* dx, int dx_pitch, void* dgb_img, int dgb_pitch,
+                     void* stream);
+
+/* ---- state path: positional encoding (nerf-pytorch embedder)  ------------------------ */
+/* out[n][0:S]=s, then for k<L: sin(2^k s), cos(2^k s); columns >= S*(1+2L) up to out_pitch
+ * are zero-filled.  fp32 in / fp32 out.                                                 */
+int s2p_posenc_fwd(const float* state, int N, int S, int L, float* out, int out_pitch, void* stream);
+
+/* ---- pooling / resize / layout ---------------------------------------------------- */
+/* F.avg_pool2d(k=3,s=2,p=1,count_include_pad=False) and its backward                   */
+int s2p_avgpool3x3s2_fwd(int dtype, const void* x, int N, int H, int W, int C, void* y, void* stream);
+int s2p_avgpool3x3s2_bwd(int dtype, const void* dy, int N, int H, int W, int C, void* dx,
+                         int accumulate, void* stream);
+/* F.max_pool2d(2,2) (floor) and backward fused with the producer's ReLU mask            */
+int s2p_maxpool2x2_fwd(int dtype, const void* x, int N, int H, int W, int C, void* y, void* stream);
+int s2p_maxpool2x2_bwd(int dtype, const void* dy, const void* x, int N, int H, int W, int C,
+                       void* dx, void* stream);
+/* F.interpolate(mode='nearest') on NHWC                                                 */
+int s2p_resize_nearest(int dtype, const void* x, int N, int H, int W, int C, void* y, int Ho, int Wo,
+                       void* stream);
+/* fp32 NCHW [N,C,H,W]  ->  NHWC dtype with channel pitch (zero pad), written at channel
+ * offset c_off; and back.                                                               */
+int s2p_nchw_to_nhwc(int dtype, const float* x, int N, int C, int H, int W, void* y, int y_pitch,
+                     int c_off, int zero_pad, void* stream);
+int s2p_nhwc_to_nchw(int dtype, const void* x, int x_pitch, int c_off, int N, int C, int H, int W,
+                     float* y, int accumulate, void* stream);
+/* generic cast copy between dtypes (n elements)                                         */
+int s2p_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, void* stream);
+
+/* ---- losses (forward value + gradient seed in one pass) ---------------------------- */
+/* loss_out[0] += scale * sum|a-b| ; if grad_a: grad_a = (accumulate? grad_a:0) + scale*sign(a-b)
+ * a,b: `count` elements each (dtype)                                                    */
+int s2p_l1_loss(int dtype, const void* a, const void* b, int64_t count, float scale,
+                float* loss_out, void* grad_a, int accumulate, void* stream);
+/* hinge terms on a D logit map x (count elements):
+ *   mode 0: loss += scale*sum(relu(1+x)), grad = scale*(1+x>0)      (D on fake)
+ *   mode 1: loss += scale*sum(relu(1-x)), grad = -scale*(1-x>0)     (D on real)
+ *   mode 2: loss += -scale*sum(x),       grad = -scale              (G)                */
+int s2p_hinge_loss(int dtype, const void* x, int64_t count, int mode, float scale,
+                   float* loss_out, void* grad_x, void* stream);
+
+/* ---- optimizer + weight packing ---------------------------------------------------- */
+/* torch.optim.Adam step on flat fp32 buffers; g is multiplied by grad_scale first.      */
+int s2p_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, int step, float grad_scale, void* stream);
+/* one packing job: src fp32 [R][T][C] (channels-last master weight: R rows, T taps, C
+ * channels) -> dst_fwd[r][t][c] (row length T*Cpad, zero pad c>=C)  and/or
+ * dst_bwd[c][t][r_off + r] (row length T*Rrow; untouched elements must be pre-zeroed)    */
+typedef struct {
+  const float* src; void* dst_fwd; void* dst_bwd;
+  int32_t R, T, C;
+  int32_t Cpad;        /* fwd: padded channel count                                     */
+  int32_t Rrow;        /* bwd: row length (in r) of the transposed matrix               */
+  int32_t r_off;       /* bwd: column offset of this job inside a fused matrix          */
+  int32_t dtype;
+} s2p_pack_job;
+/* jobs: DEVICE array of n_jobs descriptors (caller-owned)                               */
+int s2p_pack_weights(const s2p_pack_job* jobs, int n_jobs, int max_elems, void* stream);
+
+/* ---- small elementwise helpers ------------------------------------------------------ */
+/* dx = dy * act'(y)   (y = activation OUTPUT)                                           */
+int s2p_act_bwd(int dtype, const void* dy, const void* y, int64_t n, int act, float slope, void* dx,
+                void* stream);
+/* x *= *scale  (device fp32 scalar: applies an upstream grad_output without a host sync) */
+int s2p_scale(int dtype, void* x, int64_t n, const float* scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

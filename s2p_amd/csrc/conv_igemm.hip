@@ -1,0 +1,409 @@
+// Implicit-GEMM 2-D convolution family for gfx950 (MI355X), NHWC activations.
+//
+// One "gather GEMM" kernel computes  D[co][m] = sum_{t,c} Wp[co][wt(t)][c] * X[n, qy*is+dy(t), qx*is+dx(t), c]
+// for GEMM pixel m=(n,qy,qx) and stores D at output pixel (n, qy*os+oy0, qx*os+ox0).  With the tap table
+// (dy,dx,wt) chosen on the host this one kernel is
+//   * conv2d forward (any KHxKW / stride / zero or reflect pad / groups),
+//   * conv_transpose2d forward and strided-conv dgrad (one launch per output phase: sub-pixel decomposition,
+//     so no MFMA lane ever multiplies a structural zero),
+//   * stride-1 conv dgrad and conv_transpose dgrad (plain gather with the transposed packed weight).
+// MFMA: A operand = packed weights (rows = co, K contiguous), B operand = gathered pixels (K contiguous in NHWC),
+// v_mfma_f32_32x32x16_bf16 (bf16) or v_mfma_f32_32x32x2_f32 (exact fp32 parity path).  LDS rows are 64 B of K
+// padded to 80 B (conflict-free ds_read_b128); global->register->LDS staging, double buffered, one barrier
+// per K step; epilogue goes through LDS so every global store is a full 16-B chunk along the channel axis.
+#include "s2p_common.h"
+
+#define MAX_TAPS 64
+
+struct GatherArgs {
+  const void* x; const void* w; const float* bias; const void* aux; void* y;
+  int M, Hi, Wi, Qh, Qw;
+  int Cin, x_pitch, x_gstride;
+  int Cout, Cst, y_pitch, y_gstride;
+  int Ho, Wo;
+  int istride, ostride, oy0, ox0;
+  int T, Ktot, w_row;
+  long long w_gstride;
+  int reflect, act, epi, gact;
+  float slope, gslope;
+  int npix_tiles, nco_tiles;
+  int tap[MAX_TAPS];   // (wt << 16) | ((dx & 0xff) << 8) | (dy & 0xff)
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<__bf16> { static constexpr int BK = 32; };
+template <> struct Mma<float> { static constexpr int BK = 16; };
+
+template <typename T, int BCO, int BPIX, int WCO, int WPIX>
+__global__ __launch_bounds__(256, 2) void conv_gather_kernel(const GatherArgs a) {
+  constexpr int CE = DT<T>::CE;
+  constexpr int BK = Mma<T>::BK;          // 64 bytes of K per row
+  constexpr int RS = 80;                  // LDS row stride (bytes)
+  constexpr int TCO = BCO / WCO / 32, TPIX = BPIX / WPIX / 32;
+  constexpr int NLW = (BCO + 63) / 64, NLP = BPIX / 64;
+  constexpr int STAGE = (BCO + BPIX) * RS;
+  constexpr int ERS = BCO * (int)sizeof(T) + 16;      // epilogue row stride
+  constexpr int EPI = BPIX * ERS;
+  constexpr int MAIN = (2 * STAGE > EPI ? 2 * STAGE : EPI);
+  __shared__ __attribute__((aligned(16))) char smem[MAIN + BPIX * 4 + MAX_TAPS * 4];
+  int* rowoff = (int*)(smem + MAIN);
+  int* taps = rowoff + BPIX;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int g = blockIdx.y;
+
+  // XCD-aware tile order: blocks b, b+8, ... share an XCD (observed round-robin); give each XCD a
+  // contiguous run of tiles so blocks that share a pixel tile (all co tiles of it) hit the same L2.
+  int nblk = a.npix_tiles * a.nco_tiles;
+  int bid = blockIdx.x;
+  {
+    int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, k = bid >> 3;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+  }
+  const int co_tile = bid % a.nco_tiles, pix_tile = bid / a.nco_tiles;
+  const int co_base = co_tile * BCO, pix_base = pix_tile * BPIX;
+
+  if (tid < MAX_TAPS) taps[tid] = a.tap[tid];
+  const int QQ = a.Qh * a.Qw;
+  if (tid < BPIX) {
+    int m = pix_base + tid;
+    int off = -1;
+    if (m < a.M) {
+      int n = m / QQ, rr = m - n * QQ, qy = rr / a.Qw, qx = rr - qy * a.Qw;
+      off = ((n * a.Ho + qy * a.ostride + a.oy0) * a.Wo + qx * a.ostride + a.ox0);
+    }
+    rowoff[tid] = off;
+  }
+
+  // ---- per-thread staging assignment -------------------------------------------------------
+  const int jc = tid & 3;          // 16-byte chunk column inside the 64-byte K row
+  const int r0 = tid >> 2;         // row 0..63 (+64*i)
+  int k_tap, k_c;                  // (tap, channel) of this thread's chunk, advanced by BK per step
+  {
+    int k = jc * CE;
+    k_tap = k / a.Cin; k_c = k - k_tap * a.Cin;
+  }
+  int kk = jc * CE;                // linear k of this thread's chunk
+  // pixel rows handled by this thread
+  int p_py[NLP], p_px[NLP], p_base[NLP];
+  bool p_ok[NLP];
+#pragma unroll
+  for (int i = 0; i < NLP; ++i) {
+    int m = pix_base + r0 + 64 * i;
+    p_ok[i] = m < a.M;
+    int mm = p_ok[i] ? m : 0;
+    int n = mm / QQ, rr = mm - n * QQ, qy = rr / a.Qw, qx = rr - qy * a.Qw;
+    p_py[i] = qy * a.istride; p_px[i] = qx * a.istride; p_base[i] = n * a.Hi;
+  }
+  const T* xg = (const T*)a.x + (size_t)g * a.x_gstride;
+  const T* wg = (const T*)a.w + (size_t)g * a.w_gstride;
+
+  u32x4 regW[NLW], regP[NLP];
+  const int nk = (a.Ktot + BK - 1) / BK;
+
+  __syncthreads();   // taps visible
+
+  auto load_global = [&]() {
+    const bool kok = kk < a.Ktot;
+    const int ti = taps[k_tap < MAX_TAPS ? k_tap : 0];
+    const int dy = (int)(signed char)(ti & 0xff), dx = (int)(signed char)((ti >> 8) & 0xff), wt = ti >> 16;
+#pragma unroll
+    for (int i = 0; i < NLW; ++i) {
+      int row = r0 + 64 * i;
+      int co = co_base + row;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (row < BCO && co < a.Cout && kok)
+        v = *(const u32x4*)(wg + (size_t)co * a.w_row + wt * a.Cin + k_c);
+      regW[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NLP; ++i) {
+      int iy = p_py[i] + dy, ix = p_px[i] + dx;
+      if (a.reflect) {
+        iy = iy < 0 ? -iy : (iy >= a.Hi ? 2 * a.Hi - 2 - iy : iy);
+        ix = ix < 0 ? -ix : (ix >= a.Wi ? 2 * a.Wi - 2 - ix : ix);
+      }
+      bool ok = p_ok[i] && kok && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ok) v = *(const u32x4*)(xg + ((size_t)(p_base[i] + iy) * a.Wi + ix) * a.x_pitch + k_c);
+      regP[i] = v;
+    }
+    // advance to the next K step
+    kk += BK; k_c += BK;
+    while (k_c >= a.Cin) { k_c -= a.Cin; ++k_tap; }
+  };
+  auto store_lds = [&](int buf) {
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < NLW; ++i) {
+      int row = r0 + 64 * i;
+      if (row < BCO) *(u32x4*)(base + row * RS + jc * 16) = regW[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NLP; ++i) {
+      int row = BCO + r0 + 64 * i;
+      *(u32x4*)(base + row * RS + jc * 16) = regP[i];
+    }
+  };
+
+  f32x16 acc[TCO][TPIX];
+#pragma unroll
+  for (int i = 0; i < TCO; ++i)
+#pragma unroll
+    for (int j = 0; j < TPIX; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int wco0 = (wave / WPIX) * (TCO * 32);
+  const int wpix0 = (wave % WPIX) * (TPIX * 32);
+
+  if (nk > 0) {
+    load_global();
+    store_lds(0);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) load_global();
+    const char* base = smem + (kt & 1) * STAGE;
+    const char* wrow = base + (wco0 + r) * RS + h * 16;
+    const char* prow = base + (BCO + wpix0 + r) * RS + h * 16;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 af[TCO], bf[TPIX];
+#pragma unroll
+        for (int i = 0; i < TCO; ++i) af[i] = *(const bf16x8*)(wrow + i * 32 * RS + s * 32);
+#pragma unroll
+        for (int j = 0; j < TPIX; ++j) bf[j] = *(const bf16x8*)(prow + j * 32 * RS + s * 32);
+#pragma unroll
+        for (int i = 0; i < TCO; ++i)
+#pragma unroll
+          for (int j = 0; j < TPIX; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        f32x4 af[TCO], bf[TPIX];
+#pragma unroll
+        for (int i = 0; i < TCO; ++i) af[i] = *(const f32x4*)(wrow + i * 32 * RS + s * 32);
+#pragma unroll
+        for (int j = 0; j < TPIX; ++j) bf[j] = *(const f32x4*)(prow + j * 32 * RS + s * 32);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < TCO; ++i)
+#pragma unroll
+            for (int j = 0; j < TPIX; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (more) store_lds((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias + activation in registers, transpose through LDS, 16-B stores ----------
+  const float* bias = a.bias ? a.bias + (size_t)g * a.Cout : nullptr;
+#pragma unroll
+  for (int i = 0; i < TCO; ++i) {
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      int col = wco0 + 32 * i + 8 * q4 + 4 * h;     // local co of element e=0
+      float bv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int co = co_base + col + e;
+        bv[e] = (bias && co < a.Cout) ? bias[co] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < TPIX; ++j) {
+        int prow_l = wpix0 + 32 * j + r;
+        char* dst = smem + prow_l * ERS + col * (int)sizeof(T);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_fwd(acc[i][j][4 * q4 + e] + bv[e], a.act, a.slope);
+        if constexpr (sizeof(T) == 2) {
+          bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+          *(bf16x4*)dst = o;
+        } else {
+          f32x4 o = {v[0], v[1], v[2], v[3]};
+          *(f32x4*)dst = o;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int CPR = BCO / CE;
+  T* yg = (T*)a.y + (size_t)g * a.y_gstride;
+  const T* auxg = a.aux ? (const T*)a.aux + (size_t)g * a.y_gstride : nullptr;
+  for (int idx = tid; idx < BPIX * CPR; idx += 256) {
+    int row = idx / CPR, ch = idx - row * CPR;
+    int off = rowoff[row];
+    int co0 = co_base + ch * CE;
+    if (off < 0 || co0 >= a.Cst) continue;
+    Chunk<T> c;
+    c.raw = *(const u32x4*)(smem + row * ERS + ch * 16);
+    size_t go = (size_t)off * a.y_pitch + co0;
+    bool full = co0 + CE <= a.Cst;
+    if (a.epi != S2P_EPI_STORE) {
+      Chunk<T> x;
+      if (full) x.raw = *(const u32x4*)(auxg + go);
+      else {
+        x.raw = (u32x4){0u, 0u, 0u, 0u};
+        for (int e = 0; e < CE; ++e) if (co0 + e < a.Cst) x.set(e, to_f32(auxg[go + e]));
+      }
+#pragma unroll
+      for (int e = 0; e < CE; ++e) {
+        float v = c.get(e), xv = x.get(e);
+        v = (a.epi == S2P_EPI_ADD) ? v + xv : v * act_grad_from_out(xv, a.gact, a.gslope);
+        c.set(e, v);
+      }
+    }
+    if (full) *(u32x4*)(yg + go) = c.raw;
+    else for (int e = 0; e < CE; ++e) if (co0 + e < a.Cst) yg[go + e] = from_f32<T>(c.get(e));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T, int BCO, int BPIX, int WCO, int WPIX>
+static int launch_cfg(GatherArgs& a, int groups, hipStream_t st) {
+  a.npix_tiles = cdiv(a.M, BPIX);
+  a.nco_tiles = cdiv(a.Cst, BCO);
+  dim3 grid(a.npix_tiles * a.nco_tiles, groups);
+  hipLaunchKernelGGL((conv_gather_kernel<T, BCO, BPIX, WCO, WPIX>), grid, dim3(256), 0, st, a);
+  S2P_CHECK_LAUNCH("conv_gather_kernel");
+  return 0;
+}
+
+template <typename T>
+static int launch_gather(GatherArgs& a, int groups, hipStream_t st) {
+  if (a.M <= 0) return 0;
+  if (a.Cst > 64) return launch_cfg<T, 128, 128, 2, 2>(a, groups, st);
+  if (a.Cst > 32) return launch_cfg<T, 64, 128, 2, 2>(a, groups, st);
+  return launch_cfg<T, 32, 256, 1, 4>(a, groups, st);
+}
+
+static int pack_tap(int dy, int dx, int wt) { return (wt << 16) | ((dx & 0xff) << 8) | (dy & 0xff); }
+
+// geometry of one generic problem: gathered tensor (Hi,Wi,Ci,xpitch,xg), produced tensor (Ho,Wo,Co,Cst,ypitch,yg)
+struct Geo {
+  int N, Hi, Wi, Ci, xp, xg, Ho, Wo, Co, Cst, yp, yg, KH, KW, stride, pad, reflect, groups;
+  long long w_gstride; int w_row;
+};
+
+// "gather" orientation: out(oy) = sum_k in(oy*stride + k - pad)   (conv fwd, convT dgrad)
+template <typename T>
+static int run_gather(const Geo& G, const void* x, const void* w, const float* bias, const void* aux, void* y,
+                      int act, float slope, int epi, int gact, float gslope, hipStream_t st) {
+  GatherArgs a{};
+  a.x = x; a.w = w; a.bias = bias; a.aux = aux; a.y = y;
+  a.Hi = G.Hi; a.Wi = G.Wi; a.Qh = G.Ho; a.Qw = G.Wo; a.M = G.N * G.Ho * G.Wo;
+  a.Cin = G.Ci; a.x_pitch = G.xp; a.x_gstride = G.xg;
+  a.Cout = G.Co; a.Cst = G.Cst; a.y_pitch = G.yp; a.y_gstride = G.yg;
+  a.Ho = G.Ho; a.Wo = G.Wo; a.istride = G.stride; a.ostride = 1; a.oy0 = 0; a.ox0 = 0;
+  a.T = G.KH * G.KW; a.Ktot = a.T * G.Ci; a.w_row = G.w_row; a.w_gstride = G.w_gstride;
+  a.reflect = G.reflect; a.act = act; a.epi = epi; a.slope = slope; a.gact = gact; a.gslope = gslope;
+  if (a.T > MAX_TAPS) S2P_FAIL(-2, "conv: more than %d taps", MAX_TAPS);
+  for (int ky = 0; ky < G.KH; ++ky)
+    for (int kx = 0; kx < G.KW; ++kx) a.tap[ky * G.KW + kx] = pack_tap(ky - G.pad, kx - G.pad, ky * G.KW + kx);
+  return launch_gather<T>(a, G.groups, st);
+}
+
+// "scatter" orientation expressed per output phase: out(oy) = sum_k in((oy + pad - k)/stride)
+// (conv_transpose fwd, strided/unstrided conv dgrad)
+template <typename T>
+static int run_scatter(const Geo& G, const void* x, const void* w, const float* bias, const void* aux, void* y,
+                       int act, float slope, int epi, int gact, float gslope, hipStream_t st) {
+  const int s = G.stride;
+  for (int py = 0; py < s; ++py)
+    for (int px = 0; px < s; ++px) {
+      GatherArgs a{};
+      a.x = x; a.w = w; a.bias = bias; a.aux = aux; a.y = y;
+      a.Hi = G.Hi; a.Wi = G.Wi;
+      a.Qh = (G.Ho - py + s - 1) / s; a.Qw = (G.Wo - px + s - 1) / s;
+      if (a.Qh <= 0 || a.Qw <= 0) continue;
+      a.M = G.N * a.Qh * a.Qw;
+      a.Cin = G.Ci; a.x_pitch = G.xp; a.x_gstride = G.xg;
+      a.Cout = G.Co; a.Cst = G.Cst; a.y_pitch = G.yp; a.y_gstride = G.yg;
+      a.Ho = G.Ho; a.Wo = G.Wo; a.istride = 1; a.ostride = s; a.oy0 = py; a.ox0 = px;
+      a.w_row = G.w_row; a.w_gstride = G.w_gstride;
+      a.reflect = 0; a.act = act; a.epi = epi; a.slope = slope; a.gact = gact; a.gslope = gslope;
+      int t = 0;
+      for (int ky = 0; ky < G.KH; ++ky) {
+        if ((py + G.pad - ky) % s != 0) continue;
+        for (int kx = 0; kx < G.KW; ++kx) {
+          if ((px + G.pad - kx) % s != 0) continue;
+          if (t >= MAX_TAPS) S2P_FAIL(-2, "conv: more than %d taps", MAX_TAPS);
+          a.tap[t++] = pack_tap((py + G.pad - ky) / s, (px + G.pad - kx) / s, ky * G.KW + kx);
+        }
+      }
+      a.T = t; a.Ktot = t * G.Ci;
+      int rc = launch_gather<T>(a, G.groups, st);
+      if (rc) return rc;
+    }
+  return 0;
+}
+
+static int check_desc(const s2p_conv_desc* d, const char* who) {
+  if (!d) S2P_FAIL(-1, "%s: null desc", who);
+  if (d->dtype != S2P_F32 && d->dtype != S2P_BF16) S2P_FAIL(-1, "%s: bad dtype %d", who, d->dtype);
+  int ce = d->dtype == S2P_F32 ? 4 : 8;
+  if (d->Cin % ce || d->x_pitch % ce || d->y_pitch % ce || d->x_gstride % ce || d->y_gstride % ce)
+    S2P_FAIL(-1, "%s: Cin/pitches must be multiples of %d elements (Cin=%d xp=%d yp=%d)", who, ce, d->Cin,
+             d->x_pitch, d->y_pitch);
+  if (d->groups < 1 || d->stride < 1 || d->KH < 1 || d->KW < 1) S2P_FAIL(-1, "%s: bad geometry", who);
+  if (d->x_pitch < d->Cin || d->y_pitch < d->Cout) S2P_FAIL(-1, "%s: pitch smaller than channels", who);
+  if ((long long)d->N * d->Ho * d->Wo >= (1ll << 31) / 512 * 64) { /* offsets are 32-bit pixel indices */ }
+  if (d->reflect && (d->pad >= d->H || d->pad >= d->W)) S2P_FAIL(-1, "%s: reflect pad >= size", who);
+  return 0;
+}
+
+extern "C" int s2p_conv2d_fwd(const s2p_conv_desc* d, const void* x, const void* w_fwd, const float* bias,
+                              const void* aux, void* y, int act, float slope, int epi, void* stream) {
+  int rc = check_desc(d, "s2p_conv2d_fwd");
+  if (rc) return rc;
+  if (!x || !w_fwd || !y) S2P_FAIL(-1, "s2p_conv2d_fwd: null pointer");
+  if (epi != S2P_EPI_STORE && !aux) S2P_FAIL(-1, "s2p_conv2d_fwd: epi needs aux");
+  hipStream_t st = (hipStream_t)stream;
+  int ce = d->dtype == S2P_F32 ? 4 : 8;
+  Geo G{d->N, d->H, d->W, d->Cin, d->x_pitch, d->x_gstride, d->Ho, d->Wo, d->Cout,
+        /*Cst*/ d->groups == 1 ? ((d->Cout + ce - 1) / ce * ce <= d->y_pitch ? (d->Cout + ce - 1) / ce * ce : d->Cout)
+                               : d->Cout,
+        d->y_pitch, d->y_gstride, d->KH, d->KW, d->stride, d->pad, d->reflect, d->groups,
+        (long long)d->Cout * d->KH * d->KW * d->Cin, d->KH * d->KW * d->Cin};
+  if (d->transposed) {
+    if (d->reflect) S2P_FAIL(-1, "s2p_conv2d_fwd: reflect + transposed unsupported");
+    return d->dtype == S2P_F32 ? run_scatter<float>(G, x, w_fwd, bias, aux, y, act, slope, epi, 0, 0.f, st)
+                               : run_scatter<__bf16>(G, x, w_fwd, bias, aux, y, act, slope, epi, 0, 0.f, st);
+  }
+  return d->dtype == S2P_F32 ? run_gather<float>(G, x, w_fwd, bias, aux, y, act, slope, epi, 0, 0.f, st)
+                             : run_gather<__bf16>(G, x, w_fwd, bias, aux, y, act, slope, epi, 0, 0.f, st);
+}
+
+// dgrad: gathered tensor = dy (grid Ho x Wo, channels Cout), produced tensor = dx (grid H x W, channels Cin).
+// With reflect padding the produced grid is the PADDED one, (H+2p) x (W+2p): fold it with s2p_reflect_pad_bwd.
+extern "C" int s2p_conv2d_dgrad(const s2p_conv_desc* d, const void* dy, const void* w_bwd, const void* aux,
+                                void* dx, int epi, int aux_act, float slope, void* stream) {
+  int rc = check_desc(d, "s2p_conv2d_dgrad");
+  if (rc) return rc;
+  if (!dy || !w_bwd || !dx) S2P_FAIL(-1, "s2p_conv2d_dgrad: null pointer");
+  if (epi != S2P_EPI_STORE && !aux) S2P_FAIL(-1, "s2p_conv2d_dgrad: epi needs aux");
+  hipStream_t st = (hipStream_t)stream;
+  int ce = d->dtype == S2P_F32 ? 4 : 8;
+  int cout_pad = (d->Cout + ce - 1) / ce * ce;       // channels of dy actually gathered
+  if (cout_pad > d->y_pitch) S2P_FAIL(-1, "s2p_conv2d_dgrad: dy pitch %d < padded Cout %d", d->y_pitch, cout_pad);
+  int H = d->H, W = d->W, pad = d->pad;
+  if (d->reflect) { H += 2 * pad; W += 2 * pad; pad = 0; }
+  Geo G{d->N, d->Ho, d->Wo, cout_pad, d->y_pitch, d->y_gstride, H, W, d->Cin, d->Cin,
+        d->x_pitch, d->x_gstride, d->KH, d->KW, d->stride, pad, 0, d->groups,
+        (long long)d->Cin * d->KH * d->KW * cout_pad, d->KH * d->KW * cout_pad};
+  if (d->transposed)   // adjoint of a scatter is a gather
+    return d->dtype == S2P_F32 ? run_gather<float>(G, dy, w_bwd, nullptr, aux, dx, S2P_ACT_NONE, 0.f, epi, aux_act, slope, st)
+                               : run_gather<__bf16>(G, dy, w_bwd, nullptr, aux, dx, S2P_ACT_NONE, 0.f, epi, aux_act, slope, st);
+  return d->dtype == S2P_F32 ? run_scatter<float>(G, dy, w_bwd, nullptr, aux, dx, S2P_ACT_NONE, 0.f, epi, aux_act, slope, st)
+                             : run_scatter<__bf16>(G, dy, w_bwd, nullptr, aux, dx, S2P_ACT_NONE, 0.f, epi, aux_act, slope, st);
+}

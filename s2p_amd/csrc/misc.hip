@@ -1,0 +1,429 @@
+// Small HBM/latency-bound kernels of the S2P path: positional encoding, pooling, nearest resize, layout
+// conversion, loss reductions (+ gradient seeds), fused Adam, weight packing, reflect-pad adjoint.
+#include "s2p_common.h"
+#include <string.h>
+
+// ---- error plumbing ------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void s2p_set_error(const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+extern "C" const char* s2p_last_error(void) { return g_err; }
+extern "C" int s2p_version(void) { return S2P_VERSION; }
+
+static inline int grid_for(long long total, int cap = 4096) {
+  long long b = (total + 255) / 256; if (b > cap) b = cap; if (b < 1) b = 1; return (int)b;
+}
+#define GRID_STRIDE(idx, total) \
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < (total); idx += (long long)gridDim.x * 256)
+
+// ---- positional encoding ---------------------------------------------------------------------------
+__global__ void posenc_kernel(const float* s, int N, int S, int L, float* out, int pitch) {
+  long long total = (long long)N * pitch;
+  GRID_STRIDE(idx, total) {
+    int n = (int)(idx / pitch), j = (int)(idx - (long long)n * pitch);
+    float v = 0.f;
+    if (j < S) v = s[n * S + j];
+    else if (j < S * (1 + 2 * L)) {
+      int b = (j - S) / S, i = (j - S) - b * S;   // block b: 2k -> sin, 2k+1 -> cos
+      int k = b >> 1;
+      float arg = s[n * S + i] * (float)(1 << k);
+      v = (b & 1) ? cosf(arg) : sinf(arg);
+    }
+    out[idx] = v;
+  }
+}
+extern "C" int s2p_posenc_fwd(const float* state, int N, int S, int L, float* out, int out_pitch, void* stream) {
+  if (!state || !out) S2P_FAIL(-1, "s2p_posenc_fwd: null pointer");
+  if (out_pitch < S * (1 + 2 * L) || L > 30) S2P_FAIL(-1, "s2p_posenc_fwd: bad pitch/L");
+  hipLaunchKernelGGL(posenc_kernel, dim3(grid_for((long long)N * out_pitch)), dim3(256), 0, (hipStream_t)stream,
+                     state, N, S, L, out, out_pitch);
+  S2P_CHECK_LAUNCH("posenc_kernel");
+  return 0;
+}
+
+// ---- pooling -----------------------------------------------------------------------------------------
+template <typename T>
+__global__ void avgpool_fwd_kernel(const T* x, int N, int H, int W, int C, T* y, int Ho, int Wo) {
+  long long total = (long long)N * Ho * Wo * C;
+  GRID_STRIDE(idx, total) {
+    int c = (int)(idx % C); long long p = idx / C;
+    int ox = (int)(p % Wo); p /= Wo; int oy = (int)(p % Ho); int n = (int)(p / Ho);
+    float s = 0.f; int cnt = 0;
+    for (int ky = 0; ky < 3; ++ky) {
+      int iy = oy * 2 - 1 + ky; if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        int ix = ox * 2 - 1 + kx; if (ix < 0 || ix >= W) continue;
+        s += to_f32(x[(((size_t)n * H + iy) * W + ix) * C + c]); ++cnt;
+      }
+    }
+    y[idx] = from_f32<T>(s / (float)cnt);
+  }
+}
+template <typename T>
+__global__ void avgpool_bwd_kernel(const T* dy, int N, int H, int W, int C, T* dx, int Ho, int Wo, int accumulate) {
+  long long total = (long long)N * H * W * C;
+  GRID_STRIDE(idx, total) {
+    int c = (int)(idx % C); long long p = idx / C;
+    int ix = (int)(p % W); p /= W; int iy = (int)(p % H); int n = (int)(p / H);
+    float s = 0.f;
+    for (int oy = (iy) / 2; oy <= (iy + 1) / 2; ++oy) {     // oy*2-1 <= iy <= oy*2+1
+      if (oy < 0 || oy >= Ho) continue;
+      int y0 = oy * 2 - 1, cy = (y0 < 0 ? 2 : 3) - ((y0 + 2 >= H) ? (y0 + 3 - H) : 0);
+      for (int ox = (ix) / 2; ox <= (ix + 1) / 2; ++ox) {
+        if (ox < 0 || ox >= Wo) continue;
+        int x0 = ox * 2 - 1, cx = (x0 < 0 ? 2 : 3) - ((x0 + 2 >= W) ? (x0 + 3 - W) : 0);
+        s += to_f32(dy[(((size_t)n * Ho + oy) * Wo + ox) * C + c]) / (float)(cy * cx);
+      }
+    }
+    if (accumulate) s += to_f32(dx[idx]);
+    dx[idx] = from_f32<T>(s);
+  }
+}
+extern "C" int s2p_avgpool3x3s2_fwd(int dtype, const void* x, int N, int H, int W, int C, void* y, void* stream) {
+  int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  long long total = (long long)N * Ho * Wo * C;
+  if (dtype == S2P_F32) hipLaunchKernelGGL(avgpool_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x, N, H, W, C, (float*)y, Ho, Wo);
+  else if (dtype == S2P_BF16) hipLaunchKernelGGL(avgpool_fwd_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, N, H, W, C, (__bf16*)y, Ho, Wo);
+  else S2P_FAIL(-1, "s2p_avgpool3x3s2_fwd: bad dtype");
+  S2P_CHECK_LAUNCH("avgpool_fwd_kernel");
+  return 0;
+}
+extern "C" int s2p_avgpool3x3s2_bwd(int dtype, const void* dy, int N, int H, int W, int C, void* dx, int accumulate, void* stream) {
+  int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  long long total = (long long)N * H * W * C;
+  if (dtype == S2P_F32) hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, N, H, W, C, (float*)dx, Ho, Wo, accumulate);
+  else if (dtype == S2P_BF16) hipLaunchKernelGGL(avgpool_bwd_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dy, N, H, W, C, (__bf16*)dx, Ho, Wo, accumulate);
+  else S2P_FAIL(-1, "s2p_avgpool3x3s2_bwd: bad dtype");
+  S2P_CHECK_LAUNCH("avgpool_bwd_kernel");
+  return 0;
+}
+
+// max-pool 2x2 stride 2 (floor).  16-byte chunks along C.
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* x, int N, int H, int W, int C, T* y, int Ho, int Wo) {
+  constexpr int CE = DT<T>::CE;
+  int cpr = C / CE;
+  long long total = (long long)N * Ho * Wo * cpr;
+  GRID_STRIDE(idx, total) {
+    int ch = (int)(idx % cpr); long long p = idx / cpr;
+    int ox = (int)(p % Wo); p /= Wo; int oy = (int)(p % Ho); int n = (int)(p / Ho);
+    const T* b = x + (((size_t)n * H + oy * 2) * W + ox * 2) * C + ch * CE;
+    Chunk<T> v00, v01, v10, v11, o;
+    v00.raw = *(const u32x4*)b; v01.raw = *(const u32x4*)(b + C);
+    v10.raw = *(const u32x4*)(b + (size_t)W * C); v11.raw = *(const u32x4*)(b + (size_t)W * C + C);
+#pragma unroll
+    for (int e = 0; e < CE; ++e) o.set(e, fmaxf(fmaxf(v00.get(e), v01.get(e)), fmaxf(v10.get(e), v11.get(e))));
+    *(u32x4*)(y + (size_t)idx * CE) = o.raw;
+  }
+}
+// dx = route dy to the first arg-max of each window, times relu'(x) (x = the pooled tensor's input = relu output);
+// rows/cols of x not covered by a window (odd H/W) get zero.
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* dy, const T* x, int N, int H, int W, int C, T* dx, int Ho, int Wo) {
+  constexpr int CE = DT<T>::CE;
+  int cpr = C / CE;
+  long long total = (long long)N * H * W * cpr;
+  GRID_STRIDE(idx, total) {
+    int ch = (int)(idx % cpr); long long p = idx / cpr;
+    int ix = (int)(p % W); p /= W; int iy = (int)(p % H); int n = (int)(p / H);
+    int oy = iy >> 1, ox = ix >> 1;
+    Chunk<T> o; o.raw = (u32x4){0u, 0u, 0u, 0u};
+    if (oy < Ho && ox < Wo) {
+      const T* b = x + (((size_t)n * H + oy * 2) * W + ox * 2) * C + ch * CE;
+      Chunk<T> v[4], d;
+      v[0].raw = *(const u32x4*)b; v[1].raw = *(const u32x4*)(b + C);
+      v[2].raw = *(const u32x4*)(b + (size_t)W * C); v[3].raw = *(const u32x4*)(b + (size_t)W * C + C);
+      d.raw = *(const u32x4*)(dy + ((((size_t)n * Ho + oy) * Wo + ox) * C + ch * CE));
+      int me = (iy & 1) * 2 + (ix & 1);
+#pragma unroll
+      for (int e = 0; e < CE; ++e) {
+        float m = v[0].get(e); int am = 0;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) { float t = v[k].get(e); if (t > m) { m = t; am = k; } }
+        o.set(e, (am == me && m > 0.f) ? d.get(e) : 0.f);
+      }
+    }
+    *(u32x4*)(dx + (size_t)idx * CE) = o.raw;
+  }
+}
+extern "C" int s2p_maxpool2x2_fwd(int dtype, const void* x, int N, int H, int W, int C, void* y, void* stream) {
+  int Ho = H / 2, Wo = W / 2, ce = dtype == S2P_F32 ? 4 : 8;
+  if (C % ce) S2P_FAIL(-1, "s2p_maxpool2x2_fwd: C must be a multiple of %d", ce);
+  long long total = (long long)N * Ho * Wo * (C / ce);
+  if (dtype == S2P_F32) hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x, N, H, W, C, (float*)y, Ho, Wo);
+  else if (dtype == S2P_BF16) hipLaunchKernelGGL(maxpool_fwd_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, N, H, W, C, (__bf16*)y, Ho, Wo);
+  else S2P_FAIL(-1, "s2p_maxpool2x2_fwd: bad dtype");
+  S2P_CHECK_LAUNCH("maxpool_fwd_kernel");
+  return 0;
+}
+extern "C" int s2p_maxpool2x2_bwd(int dtype, const void* dy, const void* x, int N, int H, int W, int C, void* dx, void* stream) {
+  int Ho = H / 2, Wo = W / 2, ce = dtype == S2P_F32 ? 4 : 8;
+  if (C % ce) S2P_FAIL(-1, "s2p_maxpool2x2_bwd: C must be a multiple of %d", ce);
+  long long total = (long long)N * H * W * (C / ce);
+  if (dtype == S2P_F32) hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (const float*)x, N, H, W, C, (float*)dx, Ho, Wo);
+  else if (dtype == S2P_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dy, (const __bf16*)x, N, H, W, C, (__bf16*)dx, Ho, Wo);
+  else S2P_FAIL(-1, "s2p_maxpool2x2_bwd: bad dtype");
+  S2P_CHECK_LAUNCH("maxpool_bwd_kernel");
+  return 0;
+}
+
+// ---- nearest resize (F.interpolate mode='nearest': src = floor(dst * in/out)) -------------------------
+template <typename T>
+__global__ void resize_kernel(const T* x, int N, int H, int W, int C, T* y, int Ho, int Wo) {
+  long long total = (long long)N * Ho * Wo * C;
+  float sy = (float)H / (float)Ho, sx = (float)W / (float)Wo;
+  GRID_STRIDE(idx, total) {
+    int c = (int)(idx % C); long long p = idx / C;
+    int ox = (int)(p % Wo); p /= Wo; int oy = (int)(p % Ho); int n = (int)(p / Ho);
+    int iy = (int)floorf(oy * sy), ix = (int)floorf(ox * sx);
+    if (iy > H - 1) iy = H - 1; if (ix > W - 1) ix = W - 1;
+    y[idx] = x[(((size_t)n * H + iy) * W + ix) * C + c];
+  }
+}
+extern "C" int s2p_resize_nearest(int dtype, const void* x, int N, int H, int W, int C, void* y, int Ho, int Wo, void* stream) {
+  long long total = (long long)N * Ho * Wo * C;
+  if (dtype == S2P_F32) hipLaunchKernelGGL(resize_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x, N, H, W, C, (float*)y, Ho, Wo);
+  else if (dtype == S2P_BF16) hipLaunchKernelGGL(resize_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, N, H, W, C, (__bf16*)y, Ho, Wo);
+  else S2P_FAIL(-1, "s2p_resize_nearest: bad dtype");
+  S2P_CHECK_LAUNCH("resize_kernel");
+  return 0;
+}
+
+// ---- layout ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* x, int N, int C, int H, int W, T* y, int pitch, int c_off, int zero_pad) {
+  int span = zero_pad ? pitch : C;        // channels written per pixel (starting at c_off when !zero_pad)
+  long long total = (long long)N * H * W * span;
+  GRID_STRIDE(idx, total) {
+    int j = (int)(idx % span); long long p = idx / span;
+    int hw = (int)(p % ((long long)H * W)); int n = (int)(p / ((long long)H * W));
+    if (zero_pad) {
+      int c = j - c_off;
+      float v = (c >= 0 && c < C) ? x[((size_t)n * C + c) * H * W + hw] : 0.f;
+      y[(size_t)p * pitch + j] = from_f32<T>(v);
+    } else {
+      y[(size_t)p * pitch + c_off + j] = from_f32<T>(x[((size_t)n * C + j) * H * W + hw]);
+    }
+  }
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* x, int pitch, int c_off, int N, int C, int H, int W, float* y, int accumulate) {
+  long long total = (long long)N * C * H * W;
+  GRID_STRIDE(idx, total) {
+    int hw = (int)(idx % ((long long)H * W)); long long q = idx / ((long long)H * W);
+    int c = (int)(q % C); int n = (int)(q / C);
+    float v = to_f32(x[((size_t)n * H * W + hw) * pitch + c_off + c]);
+    y[idx] = accumulate ? y[idx] + v : v;
+  }
+}
+extern "C" int s2p_nchw_to_nhwc(int dtype, const float* x, int N, int C, int H, int W, void* y, int y_pitch, int c_off, int zero_pad, void* stream) {
+  if (c_off + C > y_pitch) S2P_FAIL(-1, "s2p_nchw_to_nhwc: channels exceed pitch");
+  long long total = (long long)N * H * W * (zero_pad ? y_pitch : C);
+  if (dtype == S2P_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, N, C, H, W, (float*)y, y_pitch, c_off, zero_pad);
+  else if (dtype == S2P_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, N, C, H, W, (__bf16*)y, y_pitch, c_off, zero_pad);
+  else S2P_FAIL(-1, "s2p_nchw_to_nhwc: bad dtype");
+  S2P_CHECK_LAUNCH("nchw_to_nhwc_kernel");
+  return 0;
+}
+extern "C" int s2p_nhwc_to_nchw(int dtype, const void* x, int x_pitch, int c_off, int N, int C, int H, int W, float* y, int accumulate, void* stream) {
+  long long total = (long long)N * C * H * W;
+  if (dtype == S2P_F32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_pitch, c_off, N, C, H, W, y, accumulate);
+  else if (dtype == S2P_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, x_pitch, c_off, N, C, H, W, y, accumulate);
+  else S2P_FAIL(-1, "s2p_nhwc_to_nchw: bad dtype");
+  S2P_CHECK_LAUNCH("nhwc_to_nchw_kernel");
+  return 0;
+}
+
+template <typename S, typename D>
+__global__ void cast_kernel(const S* s, D* d, long long n) {
+  GRID_STRIDE(idx, n) d[idx] = from_f32<D>(to_f32(s[idx]));
+}
+extern "C" int s2p_cast(int sd, const void* src, int dd, void* dst, int64_t n, void* stream) {
+  dim3 g(grid_for(n)), b(256); hipStream_t st = (hipStream_t)stream;
+  if (sd == S2P_F32 && dd == S2P_BF16) hipLaunchKernelGGL((cast_kernel<float, __bf16>), g, b, 0, st, (const float*)src, (__bf16*)dst, (long long)n);
+  else if (sd == S2P_BF16 && dd == S2P_F32) hipLaunchKernelGGL((cast_kernel<__bf16, float>), g, b, 0, st, (const __bf16*)src, (float*)dst, (long long)n);
+  else if (sd == S2P_F32 && dd == S2P_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, st, (const float*)src, (float*)dst, (long long)n);
+  else if (sd == S2P_BF16 && dd == S2P_BF16) hipLaunchKernelGGL((cast_kernel<__bf16, __bf16>), g, b, 0, st, (const __bf16*)src, (__bf16*)dst, (long long)n);
+  else S2P_FAIL(-1, "s2p_cast: bad dtype");
+  S2P_CHECK_LAUNCH("cast_kernel");
+  return 0;
+}
+
+// ---- reflect-pad adjoint ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void reflect_fold_kernel(const T* dxp, int N, int H, int W, int C, int pad, T* dx) {
+  long long total = (long long)N * H * W * C;
+  int Hp = H + 2 * pad, Wp = W + 2 * pad;
+  GRID_STRIDE(idx, total) {
+    int c = (int)(idx % C); long long p = idx / C;
+    int x = (int)(p % W); p /= W; int y = (int)(p % H); int n = (int)(p / H);
+    int ys[3], xs[3], ny = 0, nx = 0;
+    ys[ny++] = y + pad; if (y >= 1 && y <= pad) ys[ny++] = pad - y; if (y <= H - 2 && y >= H - 1 - pad) ys[ny++] = 2 * H - 2 - y + pad;
+    xs[nx++] = x + pad; if (x >= 1 && x <= pad) xs[nx++] = pad - x; if (x <= W - 2 && x >= W - 1 - pad) xs[nx++] = 2 * W - 2 - x + pad;
+    float s = 0.f;
+    for (int a = 0; a < ny; ++a)
+      for (int b = 0; b < nx; ++b) s += to_f32(dxp[(((size_t)n * Hp + ys[a]) * Wp + xs[b]) * C + c]);
+    dx[idx] = from_f32<T>(s);
+  }
+}
+extern "C" int s2p_reflect_pad_bwd(int dtype, const void* dxp, int N, int H, int W, int C, int pad, void* dx, void* stream) {
+  long long total = (long long)N * H * W * C;
+  if (dtype == S2P_F32) hipLaunchKernelGGL(reflect_fold_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)dxp, N, H, W, C, pad, (float*)dx);
+  else if (dtype == S2P_BF16) hipLaunchKernelGGL(reflect_fold_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dxp, N, H, W, C, pad, (__bf16*)dx);
+  else S2P_FAIL(-1, "s2p_reflect_pad_bwd: bad dtype");
+  S2P_CHECK_LAUNCH("reflect_fold_kernel");
+  return 0;
+}
+
+// ---- losses ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_atomic_add(float v, float* out) {
+  __shared__ float part[4];
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+template <typename T>
+__global__ void l1_loss_kernel(const T* a, const T* b, long long count, float scale, float* loss, T* grad, int accumulate) {
+  float s = 0.f;
+  GRID_STRIDE(idx, count) {
+    float d = to_f32(a[idx]) - to_f32(b[idx]);
+    s += fabsf(d);
+    if (grad) {
+      float gsgn = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);
+      if (accumulate) gsgn += to_f32(grad[idx]);
+      grad[idx] = from_f32<T>(gsgn);
+    }
+  }
+  block_atomic_add(s * scale, loss);
+}
+extern "C" int s2p_l1_loss(int dtype, const void* a, const void* b, int64_t count, float scale, float* loss_out, void* grad_a, int accumulate, void* stream) {
+  if (!a || !b || !loss_out) S2P_FAIL(-1, "s2p_l1_loss: null pointer");
+  dim3 g(grid_for(count, 1024));
+  if (dtype == S2P_F32) hipLaunchKernelGGL(l1_loss_kernel<float>, g, dim3(256), 0, (hipStream_t)stream, (const float*)a, (const float*)b, (long long)count, scale, loss_out, (float*)grad_a, accumulate);
+  else if (dtype == S2P_BF16) hipLaunchKernelGGL(l1_loss_kernel<__bf16>, g, dim3(256), 0, (hipStream_t)stream, (const __bf16*)a, (const __bf16*)b, (long long)count, scale, loss_out, (__bf16*)grad_a, accumulate);
+  else S2P_FAIL(-1, "s2p_l1_loss: bad dtype");
+  S2P_CHECK_LAUNCH("l1_loss_kernel");
+  return 0;
+}
+template <typename T>
+__global__ void hinge_kernel(const T* x, long long count, int mode, float scale, float* loss, T* grad) {
+  float s = 0.f;
+  GRID_STRIDE(idx, count) {
+    float v = to_f32(x[idx]), l, gr;
+    if (mode == 0) { float t = 1.f + v; l = t > 0.f ? t : 0.f; gr = t > 0.f ? scale : 0.f; }
+    else if (mode == 1) { float t = 1.f - v; l = t > 0.f ? t : 0.f; gr = t > 0.f ? -scale : 0.f; }
+    else { l = -v; gr = -scale; }
+    s += l;
+    if (grad) grad[idx] = from_f32<T>(gr);
+  }
+  block_atomic_add(s * scale, loss);
+}
+extern "C" int s2p_hinge_loss(int dtype, const void* x, int64_t count, int mode, float scale, float* loss_out, void* grad_x, void* stream) {
+  if (!x || !loss_out || mode < 0 || mode > 2) S2P_FAIL(-1, "s2p_hinge_loss: bad argument");
+  dim3 g(grid_for(count, 1024));
+  if (dtype == S2P_F32) hipLaunchKernelGGL(hinge_kernel<float>, g, dim3(256), 0, (hipStream_t)stream, (const float*)x, (long long)count, mode, scale, loss_out, (float*)grad_x);
+  else if (dtype == S2P_BF16) hipLaunchKernelGGL(hinge_kernel<__bf16>, g, dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (long long)count, mode, scale, loss_out, (__bf16*)grad_x);
+  else S2P_FAIL(-1, "s2p_hinge_loss: bad dtype");
+  S2P_CHECK_LAUNCH("hinge_kernel");
+  return 0;
+}
+
+// ---- fused Adam over a flat fp32 buffer (28 B / parameter of HBM traffic) ----------------------------------
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, long long n4, long long n, float lr_bc1,
+                            float beta1, float beta2, float eps, float inv_sqrt_bc2, float gscale) {
+  GRID_STRIDE(idx, n4) {
+    long long i = idx * 4;
+    if (i + 4 <= n) {
+      f32x4 pv = *(f32x4*)(p + i), gv = *(const f32x4*)(g + i), mv = *(f32x4*)(m + i), vv = *(f32x4*)(v + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float gg = gv[e] * gscale;
+        mv[e] = beta1 * mv[e] + (1.f - beta1) * gg;
+        vv[e] = beta2 * vv[e] + (1.f - beta2) * gg * gg;
+        pv[e] -= lr_bc1 * mv[e] / (sqrtf(vv[e]) * inv_sqrt_bc2 + eps);
+      }
+      *(f32x4*)(p + i) = pv; *(f32x4*)(m + i) = mv; *(f32x4*)(v + i) = vv;
+    } else {
+      for (long long k = i; k < n; ++k) {
+        float gg = g[k] * gscale;
+        m[k] = beta1 * m[k] + (1.f - beta1) * gg;
+        v[k] = beta2 * v[k] + (1.f - beta2) * gg * gg;
+        p[k] -= lr_bc1 * m[k] / (sqrtf(v[k]) * inv_sqrt_bc2 + eps);
+      }
+    }
+  }
+}
+extern "C" int s2p_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step, float grad_scale, void* stream) {
+  if (!p || !g || !m || !v || step < 1) S2P_FAIL(-1, "s2p_adam_step: bad argument");
+  if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) S2P_FAIL(-1, "s2p_adam_step: buffers must be 16-byte aligned");
+  double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  long long n4 = (n + 3) / 4;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n4, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, (long long)n,
+                     (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), grad_scale);
+  S2P_CHECK_LAUNCH("adam_kernel");
+  return 0;
+}
+
+// ---- weight packing: fp32 channels-last master [R][T][C] -> compute dtype, both GEMM orientations ----------
+// fwd: dst_fwd[r][t][c] (row length T*Cpad, zeros for c >= C);  bwd: dst_bwd[c][t][r_off + r] (row length
+// T*Rrow; rows c >= C and columns outside [r_off, r_off+R) are never written: the caller pre-zeroes them once).
+template <typename T>
+__device__ void pack_one(const s2p_pack_job& j, int part, int nparts) {
+  if (j.dst_fwd) {
+    long long tot = (long long)j.R * j.T * j.Cpad;
+    T* d = (T*)j.dst_fwd;
+    for (long long i = (long long)part * 256 + threadIdx.x; i < tot; i += (long long)nparts * 256) {
+      int c = (int)(i % j.Cpad); long long rt = i / j.Cpad;
+      d[i] = from_f32<T>(c < j.C ? j.src[rt * j.C + c] : 0.f);
+    }
+  }
+  if (j.dst_bwd) {
+    long long tot = (long long)j.C * j.T * j.R;
+    T* d = (T*)j.dst_bwd;
+    for (long long i = (long long)part * 256 + threadIdx.x; i < tot; i += (long long)nparts * 256) {
+      int r = (int)(i % j.R); long long ct = i / j.R;
+      int t = (int)(ct % j.T), c = (int)(ct / j.T);
+      d[((long long)c * j.T + t) * j.Rrow + j.r_off + r] = from_f32<T>(j.src[((long long)r * j.T + t) * j.C + c]);
+    }
+  }
+}
+__global__ void pack_kernel(const s2p_pack_job* jobs) {
+  const s2p_pack_job j = jobs[blockIdx.y];
+  if (j.dtype == S2P_F32) pack_one<float>(j, blockIdx.x, gridDim.x);
+  else pack_one<__bf16>(j, blockIdx.x, gridDim.x);
+}
+extern "C" int s2p_pack_weights(const s2p_pack_job* jobs, int n_jobs, int max_elems, void* stream) {
+  if (!jobs || n_jobs <= 0) S2P_FAIL(-1, "s2p_pack_weights: bad argument");
+  int parts = (max_elems + 256 * 8 - 1) / (256 * 8); if (parts < 1) parts = 1; if (parts > 64) parts = 64;
+  hipLaunchKernelGGL(pack_kernel, dim3(parts, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs);
+  S2P_CHECK_LAUNCH("pack_kernel");
+  return 0;
+}
+
+// ---- activation backward / scaling -----------------------------------------------------------------------
+template <typename T>
+__global__ void act_bwd_kernel(const T* dy, const T* y, long long n, int act, float slope, T* dx) {
+  GRID_STRIDE(idx, n) dx[idx] = from_f32<T>(to_f32(dy[idx]) * act_grad_from_out(to_f32(y[idx]), act, slope));
+}
+extern "C" int s2p_act_bwd(int dtype, const void* dy, const void* y, int64_t n, int act, float slope, void* dx, void* stream) {
+  if (dtype == S2P_F32) hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (const float*)y, (long long)n, act, slope, (float*)dx);
+  else if (dtype == S2P_BF16) hipLaunchKernelGGL(act_bwd_kernel<__bf16>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dy, (const __bf16*)y, (long long)n, act, slope, (__bf16*)dx);
+  else S2P_FAIL(-1, "s2p_act_bwd: bad dtype");
+  S2P_CHECK_LAUNCH("act_bwd_kernel");
+  return 0;
+}
+// x *= *scale (device scalar, fp32) -- applies an upstream scalar grad_output without a host sync
+template <typename T>
+__global__ void scale_kernel(T* x, long long n, const float* scale) {
+  float s = *scale;
+  GRID_STRIDE(idx, n) x[idx] = from_f32<T>(to_f32(x[idx]) * s);
+}
+extern "C" int s2p_scale(int dtype, void* x, int64_t n, const float* scale, void* stream) {
+  if (dtype == S2P_F32) hipLaunchKernelGGL(scale_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (float*)x, (long long)n, scale);
+  else if (dtype == S2P_BF16) hipLaunchKernelGGL(scale_kernel<__bf16>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (__bf16*)x, (long long)n, scale);
+  else S2P_FAIL(-1, "s2p_scale: bad dtype");
+  S2P_CHECK_LAUNCH("scale_kernel");
+  return 0;
+}

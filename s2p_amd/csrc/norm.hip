@@ -1,0 +1,281 @@
+// InstanceNorm + MAT/SPADE modulation for NHWC tensors on gfx950.  HBM-bound: every tensor is touched with
+// 16-byte chunks along the contiguous channel axis; per-(n,c) reductions are done per thread over a pixel
+// stripe, then across stripes through LDS, then across blocks with one fp32 atomic per (n,c,quantity).
+//
+//   stats[n][c] = { sum x, sum x^2 }   (raw moments; consumers derive mean / rstd; this form lets a
+//                                       producer epilogue accumulate the moments instead of a stats pass)
+//   y  = act( xhat * (1 + g_img + g_st) + (b_img + b_st) ),   xhat = (x - mean) * rstd
+#include "s2p_common.h"
+
+struct NormArgs {
+  const void* x; const void* da; const void* gb; const float* gbst; const float* stats; float* sums;
+  void* y; void* dgb;
+  int N, HW, C, x_pitch, da_pitch, gb_pitch, gbst_pitch, y_pitch, dgb_pitch;
+  int act; float slope, eps;
+  int psplit, rows_per_split;
+};
+
+__device__ __forceinline__ void mean_rstd(const float* stats, int n, int C, int c, int HW, float eps,
+                                          float& mean, float& rstd) {
+  float s = stats[((size_t)n * C + c) * 2], ss = stats[((size_t)n * C + c) * 2 + 1];
+  float inv = 1.f / (float)HW;
+  mean = s * inv;
+  float var = ss * inv - mean * mean;
+  rstd = rsqrtf((var > 0.f ? var : 0.f) + eps);
+}
+
+// ------------------------------------------------------------------------------------------------
+// reductions: block = (channel slab of 64, image n, pixel split).  MODE 0: moments. MODE 1: backward sums.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void in_reduce_kernel(const NormArgs a) {
+  constexpr int CE = DT<T>::CE;
+  constexpr int CS = 64;                 // channels per block
+  constexpr int NCH = CS / CE;           // chunk columns: 8 (bf16) / 16 (fp32)
+  constexpr int PR = 256 / NCH;          // pixel rows in flight: 32 / 16
+  constexpr int NQ = MODE == 0 ? 2 : 4;
+  __shared__ float red[PR][CS + 1];
+  const int tid = threadIdx.x, cc = tid % NCH, pr = tid / NCH;
+  const int n = blockIdx.y, c0 = blockIdx.x * CS + cc * CE;
+  const bool cok = c0 < a.C;
+  const int p_begin = blockIdx.z * a.rows_per_split;
+  int p_end = p_begin + a.rows_per_split;
+  if (p_end > a.HW) p_end = a.HW;
+
+  float q[NQ][CE];
+#pragma unroll
+  for (int k = 0; k < NQ; ++k)
+#pragma unroll
+    for (int e = 0; e < CE; ++e) q[k][e] = 0.f;
+
+  float mean[CE], rstd[CE], gs[CE], bs[CE];
+  if (MODE == 1 && cok) {
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+      mean_rstd(a.stats, n, a.C, c0 + e, a.HW, a.eps, mean[e], rstd[e]);
+      gs[e] = 1.f + (a.gbst ? a.gbst[(size_t)n * a.gbst_pitch + c0 + e] : 0.f);
+      bs[e] = a.gbst ? a.gbst[(size_t)n * a.gbst_pitch + a.C + c0 + e] : 0.f;
+    }
+  }
+  if (cok) {
+    const T* xb = (const T*)a.x + (size_t)n * a.HW * a.x_pitch + c0;
+    for (int p = p_begin + pr; p < p_end; p += PR) {
+      Chunk<T> xv; xv.raw = *(const u32x4*)(xb + (size_t)p * a.x_pitch);
+      if (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < CE; ++e) { float v = xv.get(e); q[0][e] += v; q[1][e] += v * v; }
+      } else {
+        Chunk<T> dv; dv.raw = *(const u32x4*)((const T*)a.da + ((size_t)n * a.HW + p) * a.da_pitch + c0);
+        Chunk<T> gv, bv;
+        if (a.gb) {
+          const T* gp = (const T*)a.gb + ((size_t)n * a.HW + p) * a.gb_pitch + c0;
+          gv.raw = *(const u32x4*)gp; bv.raw = *(const u32x4*)(gp + a.C);
+        }
+#pragma unroll
+        for (int e = 0; e < CE; ++e) {
+          float xh = (xv.get(e) - mean[e]) * rstd[e];
+          float gg = gs[e] + (a.gb ? gv.get(e) : 0.f);
+          float bb = bs[e] + (a.gb ? bv.get(e) : 0.f);
+          float yv = xh * gg + bb;
+          float dy = dv.get(e) * act_grad_from_out(yv, a.act == S2P_ACT_TANH ? S2P_ACT_NONE : a.act, a.slope);
+          float dxh = dy * gg;
+          q[0][e] += dxh; q[1][e] += dxh * xh; q[2][e] += dy * xh; q[3][e] += dy;
+        }
+      }
+    }
+  }
+  // cross-stripe reduction through LDS, one quantity at a time
+  float* out = MODE == 0 ? (float*)a.stats : a.sums;
+#pragma unroll
+  for (int k = 0; k < NQ; ++k) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < CE; ++e) red[pr][cc * CE + e] = q[k][e];
+    __syncthreads();
+    if (tid < CS) {
+      float s = 0.f;
+#pragma unroll 4
+      for (int i = 0; i < PR; ++i) s += red[i][tid];
+      int c = blockIdx.x * CS + tid;
+      if (c < a.C) atomicAdd(out + ((size_t)n * a.C + c) * NQ + k, s);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// elementwise passes.  MODE 0: forward apply.  MODE 1: backward apply (dx, dgamma_img, dbeta_img).
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void in_apply_kernel(const NormArgs a) {
+  constexpr int CE = DT<T>::CE;
+  const int cpr = a.C / CE;                                  // chunks per pixel
+  const long long total = (long long)a.N * a.HW * cpr;
+  const float invHW = 1.f / (float)a.HW;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    long long pix = idx / cpr;
+    int c0 = (int)(idx - pix * cpr) * CE;
+    int n = (int)(pix / a.HW);
+    Chunk<T> xv; xv.raw = *(const u32x4*)((const T*)a.x + (size_t)pix * a.x_pitch + c0);
+    Chunk<T> gv, bv;
+    if (a.gb) {
+      const T* gp = (const T*)a.gb + (size_t)pix * a.gb_pitch + c0;
+      gv.raw = *(const u32x4*)gp; bv.raw = *(const u32x4*)(gp + a.C);
+    }
+    Chunk<T> dv;
+    if (MODE == 1) dv.raw = *(const u32x4*)((const T*)a.da + (size_t)pix * a.da_pitch + c0);
+    Chunk<T> o0, o1, o2;
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+      float mean, rstd;
+      mean_rstd(a.stats, n, a.C, c0 + e, a.HW, a.eps, mean, rstd);
+      float gg = 1.f + (a.gbst ? a.gbst[(size_t)n * a.gbst_pitch + c0 + e] : 0.f) + (a.gb ? gv.get(e) : 0.f);
+      float bb = (a.gbst ? a.gbst[(size_t)n * a.gbst_pitch + a.C + c0 + e] : 0.f) + (a.gb ? bv.get(e) : 0.f);
+      float xh = (xv.get(e) - mean) * rstd;
+      float yv = xh * gg + bb;
+      if (MODE == 0) {
+        o0.set(e, act_fwd(yv, a.act, a.slope));
+      } else {
+        float dy = dv.get(e) * act_grad_from_out(yv, a.act, a.slope);
+        float dxh = dy * gg;
+        const float* sm = a.sums + ((size_t)n * a.C + c0 + e) * 4;
+        o0.set(e, rstd * (dxh - sm[0] * invHW - xh * sm[1] * invHW));
+        o1.set(e, dy * xh);
+        o2.set(e, dy);
+      }
+    }
+    if (MODE == 0) {
+      *(u32x4*)((T*)a.y + (size_t)pix * a.y_pitch + c0) = o0.raw;
+    } else {
+      *(u32x4*)((T*)a.y + (size_t)pix * a.y_pitch + c0) = o0.raw;
+      if (a.dgb) {
+        T* dp = (T*)a.dgb + (size_t)pix * a.dgb_pitch + c0;
+        *(u32x4*)dp = o1.raw; *(u32x4*)(dp + a.C) = o2.raw;
+      }
+    }
+  }
+}
+
+// per-channel sum over pixels (bias gradient)
+template <typename T>
+__global__ __launch_bounds__(256) void channel_sum_kernel(const T* dy, long long pixels, int C, int pitch,
+                                                          float* db, int rows_per_block) {
+  constexpr int CE = DT<T>::CE;
+  constexpr int CS = 64, NCH = CS / CE, PR = 256 / NCH;
+  __shared__ float red[PR][CS + 1];
+  const int tid = threadIdx.x, cc = tid % NCH, pr = tid / NCH;
+  const int c0 = blockIdx.x * CS + cc * CE;
+  long long p0 = (long long)blockIdx.y * rows_per_block, p1 = p0 + rows_per_block;
+  if (p1 > pixels) p1 = pixels;
+  float q[CE];
+#pragma unroll
+  for (int e = 0; e < CE; ++e) q[e] = 0.f;
+  if (c0 < C)
+    for (long long p = p0 + pr; p < p1; p += PR) {
+      if (c0 + CE <= C) {
+        Chunk<T> v; v.raw = *(const u32x4*)(dy + (size_t)p * pitch + c0);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) q[e] += v.get(e);
+      } else {
+        for (int e = 0; e < CE; ++e) if (c0 + e < C) q[e] += to_f32(dy[(size_t)p * pitch + c0 + e]);
+      }
+    }
+#pragma unroll
+  for (int e = 0; e < CE; ++e) red[pr][cc * CE + e] = q[e];
+  __syncthreads();
+  if (tid < CS) {
+    float s = 0.f;
+    for (int i = 0; i < PR; ++i) s += red[i][tid];
+    int c = blockIdx.x * CS + tid;
+    if (c < C) atomicAdd(db + c, s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+static int norm_check(const char* who, int dtype, int C, int p0, int p1, int p2) {
+  if (dtype != S2P_F32 && dtype != S2P_BF16) S2P_FAIL(-1, "%s: bad dtype", who);
+  int ce = dtype == S2P_F32 ? 4 : 8;
+  if (C % ce || p0 % ce || p1 % ce || p2 % ce) S2P_FAIL(-1, "%s: C / pitches must be multiples of %d", who, ce);
+  return 0;
+}
+
+template <int MODE>
+static int launch_reduce(int dtype, NormArgs& a, hipStream_t st) {
+  int ps = a.HW / 512; if (ps < 1) ps = 1; if (ps > 16) ps = 16;
+  a.psplit = ps; a.rows_per_split = cdiv(a.HW, ps);
+  dim3 grid(cdiv(a.C, 64), a.N, ps);
+  if (dtype == S2P_F32) hipLaunchKernelGGL((in_reduce_kernel<float, MODE>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((in_reduce_kernel<__bf16, MODE>), grid, dim3(256), 0, st, a);
+  S2P_CHECK_LAUNCH("in_reduce_kernel");
+  return 0;
+}
+template <int MODE>
+static int launch_apply(int dtype, NormArgs& a, hipStream_t st) {
+  int ce = dtype == S2P_F32 ? 4 : 8;
+  long long total = (long long)a.N * a.HW * (a.C / ce);
+  int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+  if (dtype == S2P_F32) hipLaunchKernelGGL((in_apply_kernel<float, MODE>), dim3(blocks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((in_apply_kernel<__bf16, MODE>), dim3(blocks), dim3(256), 0, st, a);
+  S2P_CHECK_LAUNCH("in_apply_kernel");
+  return 0;
+}
+
+extern "C" int s2p_in_stats(int dtype, const void* x, int N, int HW, int C, int pitch, float eps, float* stats,
+                            void* stream) {
+  int rc = norm_check("s2p_in_stats", dtype, C, pitch, 0, 0); if (rc) return rc;
+  NormArgs a{}; a.x = x; a.stats = stats; a.N = N; a.HW = HW; a.C = C; a.x_pitch = pitch; a.eps = eps;
+  return launch_reduce<0>(dtype, a, (hipStream_t)stream);
+}
+
+extern "C" int s2p_in_apply_fwd(int dtype, const void* x, int N, int HW, int C, int pitch, const float* stats,
+                                const void* gb_img, int gb_pitch, const float* gb_st, int gb_st_pitch, int act,
+                                float slope, float eps, void* y, int y_pitch, void* stream) {
+  int rc = norm_check("s2p_in_apply_fwd", dtype, C, pitch, gb_pitch, y_pitch); if (rc) return rc;
+  NormArgs a{}; a.x = x; a.stats = stats; a.gb = gb_img; a.gbst = gb_st; a.y = y;
+  a.N = N; a.HW = HW; a.C = C; a.x_pitch = pitch; a.gb_pitch = gb_pitch; a.gbst_pitch = gb_st_pitch;
+  a.y_pitch = y_pitch; a.act = act; a.slope = slope; a.eps = eps;
+  return launch_apply<0>(dtype, a, (hipStream_t)stream);
+}
+
+extern "C" int s2p_in_bwd_reduce(int dtype, const void* da, int da_pitch, const void* x, int N, int HW, int C,
+                                 int pitch, const float* stats, const void* gb_img, int gb_pitch,
+                                 const float* gb_st, int gb_st_pitch, int act, float slope, float eps,
+                                 float* sums, void* stream) {
+  int rc = norm_check("s2p_in_bwd_reduce", dtype, C, pitch, gb_pitch, da_pitch); if (rc) return rc;
+  NormArgs a{}; a.x = x; a.da = da; a.stats = stats; a.gb = gb_img; a.gbst = gb_st; a.sums = sums;
+  a.N = N; a.HW = HW; a.C = C; a.x_pitch = pitch; a.da_pitch = da_pitch; a.gb_pitch = gb_pitch;
+  a.gbst_pitch = gb_st_pitch; a.act = act; a.slope = slope; a.eps = eps;
+  return launch_reduce<1>(dtype, a, (hipStream_t)stream);
+}
+
+extern "C" int s2p_in_bwd_apply(int dtype, const void* da, int da_pitch, const void* x, int N, int HW, int C,
+                                int pitch, const float* stats, const void* gb_img, int gb_pitch,
+                                const float* gb_st, int gb_st_pitch, int act, float slope, float eps,
+                                const float* sums, void* dx, int dx_pitch, void* dgb_img, int dgb_pitch,
+                                void* stream) {
+  int rc = norm_check("s2p_in_bwd_apply", dtype, C, pitch, gb_pitch, da_pitch); if (rc) return rc;
+  if (dx_pitch % (dtype == S2P_F32 ? 4 : 8) || dgb_pitch % (dtype == S2P_F32 ? 4 : 8))
+    S2P_FAIL(-1, "s2p_in_bwd_apply: bad output pitch");
+  NormArgs a{}; a.x = x; a.da = da; a.stats = stats; a.gb = gb_img; a.gbst = gb_st; a.sums = (float*)sums;
+  a.y = dx; a.dgb = dgb_img;
+  a.N = N; a.HW = HW; a.C = C; a.x_pitch = pitch; a.da_pitch = da_pitch; a.gb_pitch = gb_pitch;
+  a.gbst_pitch = gb_st_pitch; a.y_pitch = dx_pitch; a.dgb_pitch = dgb_pitch; a.act = act; a.slope = slope;
+  a.eps = eps;
+  return launch_apply<1>(dtype, a, (hipStream_t)stream);
+}
+
+extern "C" int s2p_channel_sum(int dtype, const void* dy, int64_t pixels, int C, int pitch, float* db,
+                               void* stream) {
+  if (dtype != S2P_F32 && dtype != S2P_BF16) S2P_FAIL(-1, "s2p_channel_sum: bad dtype");
+  int ce = dtype == S2P_F32 ? 4 : 8;
+  if (pitch % ce) S2P_FAIL(-1, "s2p_channel_sum: pitch must be a multiple of %d", ce);
+  if (pixels <= 0) return 0;
+  int nb = (int)((pixels + 2047) / 2048); if (nb > 256) nb = 256;
+  int rows = (int)((pixels + nb - 1) / nb);
+  dim3 grid(cdiv(C, 64), cdiv(pixels, rows));
+  if (dtype == S2P_F32)
+    hipLaunchKernelGGL(channel_sum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dy,
+                       (long long)pixels, C, pitch, db, rows);
+  else
+    hipLaunchKernelGGL(channel_sum_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)dy,
+                       (long long)pixels, C, pitch, db, rows);
+  S2P_CHECK_LAUNCH("channel_sum_kernel");
+  return 0;
+}

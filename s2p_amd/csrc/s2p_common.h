@@ -1,0 +1,83 @@
+// Shared device/host helpers for libs2p_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/s2p_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define S2P_WAVE 64
+
+// ---- error plumbing ---------------------------------------------------------
+void s2p_set_error(const char* fmt, ...);
+#define S2P_FAIL(code, ...) do { s2p_set_error(__VA_ARGS__); return (code); } while (0)
+#define S2P_CHECK_LAUNCH(name) do { hipError_t e_ = hipGetLastError(); \
+    if (e_ != hipSuccess) { s2p_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+      return -(int)e_ - 1000; } } while (0)
+
+// ---- dtype traits -----------------------------------------------------------
+template <typename T> struct DT;
+template <> struct DT<float> { static constexpr int CE = 4; static constexpr int id = S2P_F32; };
+template <> struct DT<__bf16> { static constexpr int CE = 8; static constexpr int id = S2P_BF16; };
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(__bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
+
+// 16-byte chunk <-> CE floats
+template <typename T> struct Chunk;
+template <> struct Chunk<float> {
+  u32x4 raw;
+  __device__ __forceinline__ float get(int i) const { return __builtin_bit_cast(float, raw[i]); }
+  __device__ __forceinline__ void set(int i, float v) { raw[i] = __builtin_bit_cast(unsigned, v); }
+};
+template <> struct Chunk<__bf16> {
+  u32x4 raw;
+  __device__ __forceinline__ float get(int i) const {
+    unsigned w = raw[i >> 1];
+    unsigned b = (i & 1) ? (w & 0xffff0000u) : (w << 16);
+    return __builtin_bit_cast(float, b);
+  }
+  __device__ __forceinline__ void set(int i, float v) {
+    __bf16 h = (__bf16)v;
+    unsigned short u = __builtin_bit_cast(unsigned short, h);
+    unsigned w = raw[i >> 1];
+    raw[i >> 1] = (i & 1) ? ((w & 0x0000ffffu) | ((unsigned)u << 16)) : ((w & 0xffff0000u) | u);
+  }
+};
+
+__device__ __forceinline__ float act_fwd(float v, int act, float slope) {
+  switch (act) {
+    case S2P_ACT_RELU: return v > 0.f ? v : 0.f;
+    case S2P_ACT_LRELU: return v > 0.f ? v : v * slope;
+    case S2P_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+// derivative given the activation OUTPUT (relu / lrelu preserve sign; tanh: 1-y^2)
+__device__ __forceinline__ float act_grad_from_out(float y, int act, float slope) {
+  switch (act) {
+    case S2P_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case S2P_ACT_LRELU: return y > 0.f ? 1.f : slope;
+    case S2P_ACT_TANH: return 1.f - y * y;
+    default: return 1.f;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

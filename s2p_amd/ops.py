@@ -1,0 +1,239 @@
+"""Raw (non-autograd) wrappers over the C ABI.  Tensors are explicit NHWC: shape [N, H, W, pitch] (contiguous),
+where `pitch` >= channel count and is a multiple of the 16-byte chunk (4 fp32 / 8 bf16 elements).
+
+Each wrapper cites the torch op of the SPADE-lineage model it replaces (the reference checkout itself ships no
+generator code: SURVEY.md section 0; lineage README.md:72-75).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, EPI_ADD, EPI_MUL_ACTGRAD, EPI_STORE, ConvDesc,
+                   check, chunk_elems, dtype_id, lib, ptr, stream)
+
+IN_EPS = 1e-5
+
+
+def pad_to(c, ce):
+    return (c + ce - 1) // ce * ce
+
+
+class ConvGeom:
+    """Static geometry of one conv layer (F.conv2d / F.conv_transpose2d arguments)."""
+
+    def __init__(self, cin, cout, k, stride=1, pad=0, transposed=False, reflect=False, groups=1,
+                 output_padding=0, x_gstride=0, y_gstride=0):
+        self.cin, self.cout, self.k = cin, cout, k
+        self.stride, self.pad = stride, pad
+        self.transposed, self.reflect, self.groups = transposed, reflect, groups
+        self.output_padding = output_padding
+        self.x_gstride, self.y_gstride = x_gstride, y_gstride
+
+    def out_hw(self, H, W):
+        k, s, p = self.k, self.stride, self.pad
+        if self.transposed:
+            return ((H - 1) * s - 2 * p + k + self.output_padding, (W - 1) * s - 2 * p + k + self.output_padding)
+        return ((H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1)
+
+    def desc(self, dtype, N, H, W, cin_pad, x_pitch, y_pitch):
+        Ho, Wo = self.out_hw(H, W)
+        return ConvDesc(dtype_id(dtype), N, H, W, cin_pad, x_pitch, Ho, Wo, self.cout, y_pitch,
+                        self.k, self.k, self.stride, self.pad, int(self.transposed), int(self.reflect),
+                        self.groups, self.x_gstride, self.y_gstride)
+
+
+def conv_fwd(geom, x, w_fwd, bias, cin_pad, y_pitch=None, act=ACT_NONE, slope=0.2, aux=None, epi=EPI_STORE,
+             out=None):
+    """y = act(conv(x, w) + b) [+ aux]   (F.conv2d / F.conv_transpose2d + bias + activation)"""
+    N, H, W, xp = x.shape
+    ce = chunk_elems(x.dtype)
+    Ho, Wo = geom.out_hw(H, W)
+    if y_pitch is None:
+        y_pitch = pad_to(geom.cout * geom.groups if geom.groups > 1 else geom.cout, ce)
+    y = out if out is not None else torch.empty((N, Ho, Wo, y_pitch), dtype=x.dtype, device=x.device)
+    d = geom.desc(x.dtype, N, H, W, cin_pad, xp, y_pitch)
+    check(lib().s2p_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(w_fwd), ptr(bias), ptr(aux), ptr(y), act, slope, epi,
+                               stream()), "s2p_conv2d_fwd")
+    return y
+
+
+def conv_dgrad(geom, dy, w_bwd, x_shape, cin_pad, aux=None, epi=EPI_STORE, aux_act=ACT_NONE, slope=0.2):
+    """dx of the conv (cudnn_convolution_backward_input equivalent).  For reflect-padded convs the padded-grid
+    gradient is folded back (adjoint of F.pad(mode='reflect'))."""
+    N, H, W, xp = x_shape
+    d = geom.desc(dy.dtype, N, H, W, cin_pad, xp, dy.shape[3])
+    if geom.reflect:
+        p = geom.pad
+        dxp = torch.empty((N, H + 2 * p, W + 2 * p, xp), dtype=dy.dtype, device=dy.device)
+        check(lib().s2p_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(w_bwd), None, ptr(dxp), EPI_STORE, ACT_NONE, 0.0,
+                                     stream()), "s2p_conv2d_dgrad")
+        dx = torch.empty((N, H, W, xp), dtype=dy.dtype, device=dy.device)
+        check(lib().s2p_reflect_pad_bwd(dtype_id(dy.dtype), ptr(dxp), N, H, W, xp, p, ptr(dx), stream()),
+              "s2p_reflect_pad_bwd")
+        if epi == EPI_MUL_ACTGRAD:
+            dx = act_bwd(dx, aux, aux_act, slope)
+        return dx
+    dx = torch.empty((N, H, W, xp), dtype=dy.dtype, device=dy.device)
+    if xp != cin_pad * geom.groups:
+        dx.zero_()
+    check(lib().s2p_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(w_bwd), ptr(aux), ptr(dx), epi, aux_act, slope,
+                                 stream()), "s2p_conv2d_dgrad")
+    return dx
+
+
+def conv_wgrad(geom, x, dy, dw, cin_pad, cin_real, cout_real, dw_gstride=0, splitk=0):
+    """dw += wgrad (cudnn_convolution_backward_weight equivalent); dw is an fp32 view in channels-last layout."""
+    N, H, W, xp = x.shape
+    d = geom.desc(x.dtype, N, H, W, cin_pad, xp, dy.shape[3])
+    check(lib().s2p_conv2d_wgrad(ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), cin_real, cout_real, dw_gstride, splitk,
+                                 stream()), "s2p_conv2d_wgrad")
+
+
+def channel_sum(dy, C, db):
+    """db += dy.sum over pixels (bias gradient)."""
+    pixels = dy.shape[0] * dy.shape[1] * dy.shape[2]
+    check(lib().s2p_channel_sum(dtype_id(dy.dtype), ptr(dy), pixels, C, dy.shape[3], ptr(db), stream()),
+          "s2p_channel_sum")
+
+
+def in_stats(x, C):
+    N, H, W, xp = x.shape
+    stats = torch.zeros((N, C, 2), dtype=torch.float32, device=x.device)
+    check(lib().s2p_in_stats(dtype_id(x.dtype), ptr(x), N, H * W, C, xp, IN_EPS, ptr(stats), stream()), "s2p_in_stats")
+    return stats
+
+
+def _gb_args(gb, gb_off, gb_st, st_off):
+    gbp = gb.data_ptr() + gb_off * gb.element_size() if gb is not None else None
+    gb_pitch = gb.shape[3] if gb is not None else 0
+    stp = gb_st.data_ptr() + st_off * 4 if gb_st is not None else None
+    st_pitch = gb_st.shape[1] if gb_st is not None else 0
+    return gbp, gb_pitch, stp, st_pitch
+
+
+def in_apply_fwd(x, C, stats, gb=None, gb_off=0, gb_st=None, st_off=0, act=ACT_NONE, slope=0.2):
+    """F.instance_norm(x) * (1 + gamma) + beta, then activation; gamma/beta = image map + per-sample state affine."""
+    N, H, W, xp = x.shape
+    y = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
+    gbp, gb_pitch, stp, st_pitch = _gb_args(gb, gb_off, gb_st, st_off)
+    check(lib().s2p_in_apply_fwd(dtype_id(x.dtype), ptr(x), N, H * W, C, xp, ptr(stats), gbp, gb_pitch, stp, st_pitch,
+                                 act, slope, IN_EPS, ptr(y), C, stream()), "s2p_in_apply_fwd")
+    return y
+
+
+def in_bwd(da, x, C, stats, gb=None, gb_off=0, gb_st=None, st_off=0, act=ACT_NONE, slope=0.2, dgb=None, dgb_off=0):
+    """Backward of in_apply_fwd.  Returns (dx, sums[N,C,4]); writes d(gamma_img|beta_img) into dgb at dgb_off.
+    sums[...,2] / sums[...,3] are d(gamma_st) / d(beta_st)."""
+    N, H, W, xp = x.shape
+    sums = torch.zeros((N, C, 4), dtype=torch.float32, device=x.device)
+    gbp, gb_pitch, stp, st_pitch = _gb_args(gb, gb_off, gb_st, st_off)
+    dt = dtype_id(x.dtype)
+    check(lib().s2p_in_bwd_reduce(dt, ptr(da), da.shape[3], ptr(x), N, H * W, C, xp, ptr(stats), gbp, gb_pitch, stp,
+                                  st_pitch, act, slope, IN_EPS, ptr(sums), stream()), "s2p_in_bwd_reduce")
+    dx = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
+    dgbp = dgb.data_ptr() + dgb_off * dgb.element_size() if dgb is not None else None
+    check(lib().s2p_in_bwd_apply(dt, ptr(da), da.shape[3], ptr(x), N, H * W, C, xp, ptr(stats), gbp, gb_pitch, stp,
+                                 st_pitch, act, slope, IN_EPS, ptr(sums), ptr(dx), C, dgbp,
+                                 dgb.shape[3] if dgb is not None else 0, stream()), "s2p_in_bwd_apply")
+    return dx, sums
+
+
+def posenc(state, L, pitch):
+    N, S = state.shape
+    out = torch.empty((N, pitch), dtype=torch.float32, device=state.device)
+    check(lib().s2p_posenc_fwd(ptr(state), N, S, L, ptr(out), pitch, stream()), "s2p_posenc_fwd")
+    return out
+
+
+def avgpool_fwd(x):
+    N, H, W, C = x.shape
+    y = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=x.dtype, device=x.device)
+    check(lib().s2p_avgpool3x3s2_fwd(dtype_id(x.dtype), ptr(x), N, H, W, C, ptr(y), stream()), "s2p_avgpool3x3s2_fwd")
+    return y
+
+
+def avgpool_bwd(dy, x_shape, dx=None, accumulate=False):
+    N, H, W, C = x_shape
+    if dx is None:
+        dx = torch.empty(x_shape, dtype=dy.dtype, device=dy.device)
+    check(lib().s2p_avgpool3x3s2_bwd(dtype_id(dy.dtype), ptr(dy), N, H, W, C, ptr(dx), int(accumulate), stream()),
+          "s2p_avgpool3x3s2_bwd")
+    return dx
+
+
+def maxpool_fwd(x):
+    N, H, W, C = x.shape
+    y = torch.empty((N, H // 2, W // 2, C), dtype=x.dtype, device=x.device)
+    check(lib().s2p_maxpool2x2_fwd(dtype_id(x.dtype), ptr(x), N, H, W, C, ptr(y), stream()), "s2p_maxpool2x2_fwd")
+    return y
+
+
+def maxpool_bwd(dy, x):
+    N, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    check(lib().s2p_maxpool2x2_bwd(dtype_id(x.dtype), ptr(dy), ptr(x), N, H, W, C, ptr(dx), stream()),
+          "s2p_maxpool2x2_bwd")
+    return dx
+
+
+def resize_nearest(x, Ho, Wo):
+    N, H, W, C = x.shape
+    y = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
+    check(lib().s2p_resize_nearest(dtype_id(x.dtype), ptr(x), N, H, W, C, ptr(y), Ho, Wo, stream()), "s2p_resize_nearest")
+    return y
+
+
+def nchw_to_nhwc(x, dtype, pitch, out=None, c_off=0, zero_pad=True):
+    """fp32 NCHW image -> NHWC compute-dtype tensor with zero-padded channel pitch."""
+    N, C, H, W = x.shape
+    x = x.contiguous()
+    y = out if out is not None else torch.empty((N, H, W, pitch), dtype=dtype, device=x.device)
+    check(lib().s2p_nchw_to_nhwc(dtype_id(dtype), ptr(x), N, C, H, W, ptr(y), pitch, c_off, int(zero_pad), stream()),
+          "s2p_nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x, C, c_off=0, out=None, accumulate=False):
+    N, H, W, xp = x.shape
+    y = out if out is not None else torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
+    check(lib().s2p_nhwc_to_nchw(dtype_id(x.dtype), ptr(x), xp, c_off, N, C, H, W, ptr(y), int(accumulate), stream()),
+          "s2p_nhwc_to_nchw")
+    return y
+
+
+def cast(x, dtype):
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    check(lib().s2p_cast(dtype_id(x.dtype), ptr(x), dtype_id(dtype), ptr(y), x.numel(), stream()), "s2p_cast")
+    return y
+
+
+def act_bwd(dy, y, act, slope=0.2):
+    dx = torch.empty_like(dy)
+    check(lib().s2p_act_bwd(dtype_id(dy.dtype), ptr(dy), ptr(y), dy.numel(), act, slope, ptr(dx), stream()), "s2p_act_bwd")
+    return dx
+
+
+def scale_(x, scale_dev):
+    """x *= scale (fp32 device scalar)."""
+    check(lib().s2p_scale(dtype_id(x.dtype), ptr(x), x.numel(), ptr(scale_dev), stream()), "s2p_scale")
+    return x
+
+
+def l1_loss(a, b, scale, loss_out, grad_a=None, accumulate=False):
+    """loss_out += scale * sum|a-b|; grad_a (+)= scale*sign(a-b).  a, b contiguous, same numel."""
+    check(lib().s2p_l1_loss(dtype_id(a.dtype), ptr(a), ptr(b), a.numel(), scale, ptr(loss_out), ptr(grad_a),
+                            int(accumulate), stream()), "s2p_l1_loss")
+
+
+def hinge_loss(x, count, mode, scale, loss_out, grad_x=None, x_off=0):
+    esz = x.element_size()
+    xp = x.data_ptr() + x_off * esz
+    gp = grad_x.data_ptr() + x_off * esz if grad_x is not None else None
+    _ = ptr(x)
+    check(lib().s2p_hinge_loss(dtype_id(x.dtype), xp, count, mode, scale, ptr(loss_out), gp, stream()), "s2p_hinge_loss")
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    check(lib().s2p_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale,
+                              stream()), "s2p_adam_step")

@@ -1,0 +1,298 @@
+"""Op-level parity of every HIP kernel against torch.nn.functional on CPU fp32.
+Integer/index work (pool routing, layout) must be exact; fp32 kernels within 1e-3 relative (north_star);
+bf16 kernels within a documented looser tolerance against the fp32 result of bf16-rounded inputs."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from s2p_amd import ops  # noqa: E402
+from s2p_amd._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, EPI_ADD, EPI_MUL_ACTGRAD, EPI_STORE, chunk_elems
+
+
+def nhwc(x, pitch, dtype, dev):
+    N, C, H, W = x.shape
+    y = torch.zeros(N, H, W, pitch)
+    y[..., :C] = x.permute(0, 2, 3, 1)
+    return y.to(dtype).to(dev)
+
+
+def nchw(y, C):
+    return y[..., :C].float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def pack_fwd(w, cin_pad, dtype, dev):          # [Co,Ci,kh,kw] -> [Co][T][Cin_pad]
+    Co, Ci, kh, kw = w.shape
+    p = torch.zeros(Co, kh * kw, cin_pad)
+    p[..., :Ci] = w.permute(0, 2, 3, 1).reshape(Co, kh * kw, Ci)
+    return p.to(dtype).to(dev)
+
+
+def pack_bwd(w, cin_pad, cout_pad, dtype, dev):  # [Co,Ci,kh,kw] -> [Cin_pad][T][Cout_pad]
+    Co, Ci, kh, kw = w.shape
+    p = torch.zeros(cin_pad, kh * kw, cout_pad)
+    p[:Ci, :, :Co] = w.permute(1, 2, 3, 0).reshape(Ci, kh * kw, Co)
+    return p.to(dtype).to(dev)
+
+
+def rel_err(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+TOL = {torch.float32: 1e-3, torch.bfloat16: 2e-2}
+
+CONV_CASES = [
+    # cin, cout, k, stride, pad, transposed, reflect, H, W, N
+    (3, 64, 7, 1, 3, False, True, 20, 20, 2),      # stem: reflect 7x7, thin input
+    (64, 128, 3, 2, 1, False, False, 20, 20, 2),   # down
+    (128, 256, 3, 1, 1, False, False, 9, 7, 3),    # resblock-like, ragged size
+    (256, 128, 3, 2, 1, True, False, 5, 5, 2),     # up (convT, output_padding 1)
+    (64, 3, 7, 1, 3, False, True, 12, 12, 2),      # out conv, Cout=3
+    (6, 64, 4, 2, 2, False, False, 21, 21, 2),     # PatchGAN first layer
+    (64, 128, 4, 1, 2, False, False, 6, 6, 2),     # PatchGAN stride-1 layer
+    (128, 1, 4, 1, 2, False, False, 7, 7, 2),      # PatchGAN head
+    (40, 72, 1, 1, 0, False, False, 1, 1, 64),     # linear layer as 1x1 conv (non power-of-two channels)
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(hip_device, dtype, case):
+    cin, cout, k, s, p, tr, refl, H, W, N = case
+    dev = hip_device
+    ce = chunk_elems(dtype)
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn((cin, cout, k, k) if tr else (cout, cin, k, k), generator=g) / math.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g)
+    if dtype == torch.bfloat16:      # compare against fp32 math on bf16-rounded operands
+        x = x.bfloat16().float(); w = w.bfloat16().float()
+    op = 1 if tr else 0
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+    if tr:
+        y_ref = F.conv_transpose2d(xr, wr, b, stride=s, padding=p, output_padding=op)
+    elif refl:
+        y_ref = F.conv2d(F.pad(xr, (p, p, p, p), mode="reflect"), wr, b, stride=s)
+    else:
+        y_ref = F.conv2d(xr, wr, b, stride=s, padding=p)
+    dy = torch.randn(y_ref.shape, generator=g)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+    y_ref.backward(dy)
+
+    cin_pad, cout_pad = ops.pad_to(cin, ce), ops.pad_to(cout, ce)
+    geom = ops.ConvGeom(cin, cout, k, s, p, transposed=tr, reflect=refl, output_padding=op)
+    w_std = w.permute(1, 0, 2, 3) if tr else w          # [Co,Ci,kh,kw] view of the weight
+    wf = pack_fwd(w_std, cin_pad, dtype, dev)
+    wb = pack_bwd(w_std, cin_pad, cout_pad, dtype, dev)
+    xd = nhwc(x, cin_pad, dtype, dev)
+    y = ops.conv_fwd(geom, xd, wf, b.to(dev), cin_pad)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(y, cout), y_ref.detach()) < TOL[dtype]
+    if y.shape[3] > cout:      # padded output channels are written as zeros
+        assert float(y[..., cout:].float().abs().max()) == 0.0
+
+    dyd = nhwc(dy, cout_pad, dtype, dev)
+    dx = ops.conv_dgrad(geom, dyd, wb, tuple(xd.shape), cin_pad)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(dx, cin), xr.grad) < TOL[dtype]
+
+    # wgrad -> channels-last fp32 [rows][T][cols]
+    rows, cols = (cin, cout) if tr else (cout, cin)
+    dw = torch.zeros(rows, k * k, cols, device=dev)
+    ops.conv_wgrad(geom, xd, dyd, dw, cin_pad, cin, cout)
+    torch.cuda.synchronize()
+    dw_ref = wr.grad.permute(0, 2, 3, 1).reshape(rows, k * k, cols)
+    assert rel_err(dw.cpu(), dw_ref) < TOL[dtype]
+    db = torch.zeros(cout, device=dev)
+    ops.channel_sum(dyd, cout, db)
+    assert rel_err(db.cpu(), dy.sum((0, 2, 3))) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_groups_epilogues(hip_device, dtype):
+    dev = hip_device
+    ce = chunk_elems(dtype)
+    g = torch.Generator().manual_seed(5)
+    G, cin, cout, N, H, W = 3, 16, 32, 2, 6, 5
+    x = torch.randn(N, G * cin, H, W, generator=g)
+    w = torch.randn(G * cout, cin, 3, 3, generator=g) / 12
+    b = torch.randn(G * cout, generator=g)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float(); w = w.bfloat16().float()
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+    y_ref = F.leaky_relu(F.conv2d(xr, wr, b, padding=1, groups=G), 0.2)
+    dy = torch.randn(y_ref.shape, generator=g)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+    geom = ops.ConvGeom(cin, cout, 3, 1, 1, groups=G, x_gstride=cin, y_gstride=cout)
+    wf = torch.stack([pack_fwd(w[i * cout:(i + 1) * cout], cin, dtype, dev) for i in range(G)])
+    wb = torch.stack([pack_bwd(w[i * cout:(i + 1) * cout], cin, cout, dtype, dev) for i in range(G)])
+    xd = nhwc(x, G * cin, dtype, dev)
+    y = ops.conv_fwd(geom, xd, wf, b.to(dev), cin, y_pitch=G * cout, act=ACT_LRELU, slope=0.2)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(y, G * cout), y_ref.detach()) < TOL[dtype]
+    # backward through the fused activation: dpre = dy * lrelu'(y) (s2p_act_bwd), then grouped dgrad / wgrad
+    y_ref.backward(dy)
+    dyd = nhwc(dy, G * cout, dtype, dev)
+    dpre = ops.act_bwd(dyd, y, ACT_LRELU, 0.2)
+    dx = ops.conv_dgrad(geom, dpre, wb, tuple(xd.shape), cin)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(dx, G * cin), xr.grad) < TOL[dtype]
+    dw = torch.zeros(G, cout, 9, cin, device=dev)
+    ops.conv_wgrad(geom, xd, dpre, dw, cin, cin, cout, dw_gstride=cout * 9 * cin)
+    torch.cuda.synchronize()
+    assert rel_err(dw.cpu().reshape(G * cout, 9, cin), wr.grad.permute(0, 2, 3, 1).reshape(G * cout, 9, cin)) < TOL[dtype]
+    # residual epilogue and fused producer-activation gradient epilogue
+    geom1 = ops.ConvGeom(G * cin, G * cin, 3, 1, 1)
+    w1 = torch.randn(G * cin, G * cin, 3, 3, generator=g) / 20
+    if dtype == torch.bfloat16:
+        w1 = w1.bfloat16().float()
+    wf1 = pack_fwd(w1, G * cin, dtype, dev)
+    y1 = ops.conv_fwd(geom1, xd, wf1, None, G * cin, aux=xd, epi=EPI_ADD)
+    assert rel_err(nchw(y1, G * cin), x + F.conv2d(x, w1, padding=1)) < TOL[dtype]
+    a = F.relu(x)
+    ad = nhwc(a, G * cin, dtype, dev)
+    wb1 = pack_bwd(w1, G * cin, G * cin, dtype, dev)
+    dy1 = torch.randn(N, G * cin, H, W, generator=g)
+    if dtype == torch.bfloat16:
+        dy1 = dy1.bfloat16().float()
+    dxm = ops.conv_dgrad(geom1, nhwc(dy1, G * cin, dtype, dev), wb1, tuple(xd.shape), G * cin, aux=ad,
+                         epi=EPI_MUL_ACTGRAD, aux_act=ACT_RELU)
+    ref = F.conv_transpose2d(dy1, w1, padding=1) * (a > 0).float()
+    assert rel_err(nchw(dxm, G * cin), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("modulated", [False, True])
+def test_instance_norm_mat(hip_device, dtype, modulated):
+    dev = hip_device
+    g = torch.Generator().manual_seed(11)
+    N, C, H, W = 3, 72 if dtype == torch.bfloat16 else 68, 9, 7
+    x = torch.randn(N, C, H, W, generator=g) * 2 + 0.5
+    gam = torch.randn(N, C, H, W, generator=g) * 0.5
+    bet = torch.randn(N, C, H, W, generator=g) * 0.5
+    st = torch.randn(N, 2 * C, generator=g) * 0.5
+    da = torch.randn(N, C, H, W, generator=g)
+    if dtype == torch.bfloat16:
+        x, gam, bet, da = [t.bfloat16().float() for t in (x, gam, bet, da)]
+    xr, gr, br, sr = [t.clone().requires_grad_(True) for t in (x, gam, bet, st)]
+    if modulated:
+        y_ref = F.leaky_relu(F.instance_norm(xr, eps=1e-5) * (1 + gr + sr[:, :C, None, None]) + br + sr[:, C:, None, None], 0.2)
+        act = ACT_LRELU
+    else:
+        y_ref = F.relu(F.instance_norm(xr, eps=1e-5))
+        act = ACT_RELU
+    y_ref.backward(da)
+    xd = nhwc(x, C, dtype, dev)
+    gb = torch.cat([nhwc(gam, C, dtype, dev), nhwc(bet, C, dtype, dev)], 3).contiguous() if modulated else None
+    std = st.to(dev) if modulated else None
+    stats = ops.in_stats(xd, C)
+    y = ops.in_apply_fwd(xd, C, stats, gb, 0, std, 0, act, 0.2)
+    torch.cuda.synchronize()
+    tol = TOL[dtype]
+    assert rel_err(nchw(y, C), y_ref.detach()) < tol
+    dgb = torch.empty_like(gb) if modulated else None
+    dx, sums = ops.in_bwd(nhwc(da, C, dtype, dev), xd, C, stats, gb, 0, std, 0, act, 0.2, dgb, 0)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(dx, C), xr.grad) < tol * 2
+    if modulated:
+        assert rel_err(nchw(dgb, C), gr.grad) < tol
+        assert rel_err(nchw(dgb[..., C:], C), br.grad) < tol
+        dst = torch.cat([sums[:, :, 2], sums[:, :, 3]], 1).cpu()
+        assert rel_err(dst, sr.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pool_resize_layout(hip_device, dtype):
+    dev = hip_device
+    ce = chunk_elems(dtype)
+    g = torch.Generator().manual_seed(3)
+    N, C, H, W = 2, 16, 11, 9
+    x = torch.randn(N, C, H, W, generator=g)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    xd = nhwc(x, C, dtype, dev)
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    # avg pool
+    xr = x.clone().requires_grad_(True)
+    yr = F.avg_pool2d(xr, 3, 2, 1, count_include_pad=False)
+    dy = torch.randn(yr.shape, generator=g)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+    yr.backward(dy)
+    y = ops.avgpool_fwd(xd)
+    assert rel_err(nchw(y, C), yr.detach()) < tol
+    dx = ops.avgpool_bwd(nhwc(dy, C, dtype, dev), tuple(xd.shape))
+    assert rel_err(nchw(dx, C), xr.grad) < tol
+    # max pool (+ fused relu mask): x is a relu output
+    a = F.relu(x)
+    ar = a.clone().requires_grad_(True)
+    mr = F.max_pool2d(F.relu(ar), 2, 2)
+    dm = torch.randn(mr.shape, generator=g)
+    if dtype == torch.bfloat16:
+        dm = dm.bfloat16().float()
+    mr.backward(dm)
+    ad = nhwc(a, C, dtype, dev)
+    m = ops.maxpool_fwd(ad)
+    assert torch.equal(nchw(m, C), mr.detach())
+    dxa = ops.maxpool_bwd(nhwc(dm, C, dtype, dev), ad)
+    assert torch.equal(nchw(dxa, C), ar.grad)
+    # nearest resize (exact)
+    r = ops.resize_nearest(xd, 5, 4)
+    assert torch.equal(nchw(r, C), F.interpolate(x, size=(5, 4), mode="nearest"))
+    # layout round trip
+    img = torch.randn(N, 3, H, W, generator=g)
+    d = ops.nchw_to_nhwc(img.to(dev), dtype, ce)
+    assert float(d[..., 3:].float().abs().max()) == 0.0
+    back = ops.nhwc_to_nchw(d, 3).cpu()
+    assert rel_err(back, img) < (1e-7 if dtype == torch.float32 else 1e-2)
+    # reflect pad adjoint
+    pr = x.clone().requires_grad_(True)
+    pp = F.pad(pr, (3, 3, 3, 3), mode="reflect")
+    dpp = torch.randn(pp.shape, generator=g)
+    if dtype == torch.bfloat16:
+        dpp = dpp.bfloat16().float()
+    pp.backward(dpp)
+    from s2p_amd._lib import check, dtype_id, lib, ptr, stream
+    out = torch.empty_like(xd)
+    dppd = nhwc(dpp, C, dtype, dev)
+    check(lib().s2p_reflect_pad_bwd(dtype_id(dtype), ptr(dppd), N, H, W, C, 3, ptr(out), stream()), "fold")
+    assert rel_err(nchw(out, C), pr.grad) < tol
+
+
+def test_posenc_losses_adam(hip_device):
+    dev = hip_device
+    import s2p_oracle as O
+    g = torch.Generator().manual_seed(9)
+    s = torch.randn(5, 17, generator=g)
+    pe = ops.posenc(s.to(dev), 10, 360).cpu()
+    ref = O.positional_encoding(s, 10)
+    assert rel_err(pe[:, :357], ref) < 1e-5 and float(pe[:, 357:].abs().max()) == 0
+    a = torch.randn(4, 6, 6, 8, generator=g); b = torch.randn(4, 6, 6, 8, generator=g)
+    loss = torch.zeros(1, device=dev)
+    ga = torch.empty_like(a, device=dev)
+    ops.l1_loss(a.to(dev), b.to(dev), 0.25, loss, ga)
+    assert abs(float(loss) - 0.25 * float((a - b).abs().sum())) < 1e-3
+    assert torch.equal(ga.cpu(), 0.25 * torch.sign(a - b))
+    x = torch.randn(300, generator=g)
+    for mode, fn in ((0, lambda v: F.relu(1 + v).sum()), (1, lambda v: F.relu(1 - v).sum()), (2, lambda v: -v.sum())):
+        xr = x.clone().requires_grad_(True)
+        (fn(xr) * 0.5).backward()
+        l = torch.zeros(1, device=dev); gx = torch.empty(300, device=dev)
+        ops.hinge_loss(x.to(dev), 300, mode, 0.5, l, gx)
+        assert abs(float(l) - 0.5 * float(fn(x))) < 1e-3
+        assert torch.allclose(gx.cpu(), xr.grad)
+    # Adam vs torch.optim.Adam
+    p = torch.randn(1003, generator=g); gr = torch.randn(1003, generator=g)
+    pt = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pt], lr=1e-3, betas=(0.0, 0.9), eps=1e-8)
+    pd, m, v = p.to(dev), torch.zeros(1003, device=dev), torch.zeros(1003, device=dev)
+    for step in range(1, 4):
+        pt.grad = gr.clone() * step
+        opt.step()
+        ops.adam_step(pd, (gr * step).to(dev), m, v, 1e-3, 0.0, 0.9, 1e-8, step)
+    assert rel_err(pd.cpu(), pt.detach()) < 1e-5
