@@ -170,6 +170,12 @@ int s2p_act_bwd(int dtype, const void* dy, const void* y, int64_t n, int act, fl
                 void* stream);
 /* x *= *scale  (device fp32 scalar: applies an upstream grad_output without a host sync) */
 int s2p_scale(int dtype, void* x, int64_t n, const float* scale, void* stream);
+/* out = a + b (n elements; out may alias a or b)                                         */
+int s2p_add(int dtype, const void* a, const void* b, void* out, int64_t n, void* stream);
+/* dst[p][dst_off+c] (+)= src[p][src_off+c] for c<C, p<pixels  (torch.cat(dim=1) on NHWC and
+ * its backward slice)                                                                   */
+int s2p_copy_channels(int dtype, const void* src, int src_pitch, int src_off, void* dst,
+                      int dst_pitch, int dst_off, int C, int64_t pixels, int accumulate, void* stream);
 
 #ifdef __cplusplus
 }

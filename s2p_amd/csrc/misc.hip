@@ -427,3 +427,36 @@ extern "C" int s2p_scale(int dtype, void* x, int64_t n, const float* scale, void
   S2P_CHECK_LAUNCH("scale_kernel");
   return 0;
 }
+
+// ---- elementwise add and channel-slice copy ---------------------------------------------------------------
+template <typename T>
+__global__ void add_kernel(const T* a, const T* b, T* out, long long n) {
+  GRID_STRIDE(idx, n) out[idx] = from_f32<T>(to_f32(a[idx]) + to_f32(b[idx]));
+}
+extern "C" int s2p_add(int dtype, const void* a, const void* b, void* out, int64_t n, void* stream) {
+  if (dtype == S2P_F32) hipLaunchKernelGGL(add_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)a, (const float*)b, (float*)out, (long long)n);
+  else if (dtype == S2P_BF16) hipLaunchKernelGGL(add_kernel<__bf16>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)a, (const __bf16*)b, (__bf16*)out, (long long)n);
+  else S2P_FAIL(-1, "s2p_add: bad dtype");
+  S2P_CHECK_LAUNCH("add_kernel");
+  return 0;
+}
+// dst[p][dst_off + c] (+)= src[p][src_off + c], c < C, p < pixels  (torch.cat along channels / its backward slice)
+template <typename T>
+__global__ void copy_channels_kernel(const T* src, int sp, int so, T* dst, int dp, int d_o, int C, long long pixels, int accumulate) {
+  long long total = pixels * C;
+  GRID_STRIDE(idx, total) {
+    long long p = idx / C; int c = (int)(idx - p * C);
+    float v = to_f32(src[p * sp + so + c]);
+    if (accumulate) v += to_f32(dst[p * dp + d_o + c]);
+    dst[p * dp + d_o + c] = from_f32<T>(v);
+  }
+}
+extern "C" int s2p_copy_channels(int dtype, const void* src, int src_pitch, int src_off, void* dst, int dst_pitch, int dst_off,
+                                 int C, int64_t pixels, int accumulate, void* stream) {
+  long long total = (long long)pixels * C;
+  if (dtype == S2P_F32) hipLaunchKernelGGL(copy_channels_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)src, src_pitch, src_off, (float*)dst, dst_pitch, dst_off, C, (long long)pixels, accumulate);
+  else if (dtype == S2P_BF16) hipLaunchKernelGGL(copy_channels_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)src, src_pitch, src_off, (__bf16*)dst, dst_pitch, dst_off, C, (long long)pixels, accumulate);
+  else S2P_FAIL(-1, "s2p_copy_channels: bad dtype");
+  S2P_CHECK_LAUNCH("copy_channels_kernel");
+  return 0;
+}

@@ -38,8 +38,10 @@ template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return
 template <typename T> struct Chunk;
 template <> struct Chunk<float> {
   u32x4 raw;
-  __device__ __forceinline__ float get(int i) const { return __builtin_bit_cast(float, raw[i]); }
-  __device__ __forceinline__ void set(int i, float v) { raw[i] = __builtin_bit_cast(unsigned, v); }
+  // NB: bit_cast applied directly to a vector-element lvalue is miscompiled by hipcc 7.2 (always element 0):
+  // go through a scalar temporary.
+  __device__ __forceinline__ float get(int i) const { unsigned u = raw[i]; return __uint_as_float(u); }
+  __device__ __forceinline__ void set(int i, float v) { unsigned u = __float_as_uint(v); raw[i] = u; }
 };
 template <> struct Chunk<__bf16> {
   u32x4 raw;

@@ -237,3 +237,22 @@ def hinge_loss(x, count, mode, scale, loss_out, grad_x=None, x_off=0):
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     check(lib().s2p_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale,
                               stream()), "s2p_adam_step")
+
+
+def add(a, b, out=None):
+    out = out if out is not None else torch.empty_like(a)
+    check(lib().s2p_add(dtype_id(a.dtype), ptr(a), ptr(b), ptr(out), a.numel(), stream()), "s2p_add")
+    return out
+
+
+def copy_channels(src, src_off, dst, dst_off, C, accumulate=False, src_rows=None, dst_row0=0, src_row0=0):
+    """dst[dst_row0 + p, ..., dst_off:dst_off+C] (+)= src[src_row0 + p, ..., src_off:src_off+C] over `src_rows` images."""
+    n_img = src.shape[0] if src_rows is None else src_rows
+    ppi = src.shape[1] * src.shape[2]
+    sp, dp = src.shape[3], dst.shape[3]
+    sptr = src.data_ptr() + src_row0 * ppi * sp * src.element_size()
+    dptr = dst.data_ptr() + dst_row0 * ppi * dp * dst.element_size()
+    _ = ptr(src), ptr(dst)
+    check(lib().s2p_copy_channels(dtype_id(src.dtype), sptr, sp, src_off, dptr, dp, dst_off, C, n_img * ppi,
+                                  int(accumulate), stream()), "s2p_copy_channels")
+    return dst

@@ -284,7 +284,7 @@ def test_posenc_losses_adam(hip_device):
         (fn(xr) * 0.5).backward()
         l = torch.zeros(1, device=dev); gx = torch.empty(300, device=dev)
         ops.hinge_loss(x.to(dev), 300, mode, 0.5, l, gx)
-        assert abs(float(l) - 0.5 * float(fn(x))) < 1e-3
+        assert float(l) == pytest.approx(0.5 * float(fn(x)), rel=1e-5, abs=1e-3), (mode, float(l))
         assert torch.allclose(gx.cpu(), xr.grad)
     # Adam vs torch.optim.Adam
     p = torch.randn(1003, generator=g); gr = torch.randn(1003, generator=g)
