@@ -1,0 +1,242 @@
+"""bench.py -- BASELINE.json metric: G+D train-step images/sec at 84x84, bs=64/GPU, on 1/2/4/8 MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = run_generator_one_step + run_discriminator_one_step (hinge GAN + feature matching + VGG19 perceptual +
+pixel L1, both Adam updates) on one synthetic batch of 64 (prev_image, state, image) triples per GPU, bf16 compute /
+fp32 accumulate, inputs resident in HBM before the timed region (BASELINE.json configs[2]).  Data-parallel over ranks
+(weak scaling: 64 images per GPU), one RCCL all-reduce of each flat gradient buffer per step.
+
+Prints ONE JSON line (rank 0) with the driver contract fields plus
+  "roofline":     in-situ HIP-event timing of the MFMA conv launches of one instrumented step: achieved
+                  algorithmic TFLOP/s of the dominant kernel family vs the dense bf16 MFMA peak;
+  "cpu_baseline": the CPU oracle (oracle/s2p_oracle.py, torch fp32 on the host cores) timed on a bounded sample of
+                  the same workload -- a reported baseline, never the thing shipped.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--size", type=int, default=84)
+    ap.add_argument("--env_type", type=str, default="cheetah")
+    ap.add_argument("--precision", type=str, default="bf16")
+    ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, state_dim):
+    """Oracle G+D train step (losses, both backward passes, both Adam updates) on the host cores, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import s2p_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    spec = O.Spec(state_dim=state_dim)
+    pg = O.init_params(O.generator_param_shapes(spec), 1)
+    pd = O.init_params(O.discriminator_param_shapes(spec), 2)
+    pv = O.init_params(O.vgg_param_shapes(), 3, kaiming=True)
+    g = torch.Generator().manual_seed(1234)
+    B = args.cpu_batch
+    prev = torch.rand(B, 3, args.size, args.size, generator=g) * 2 - 1
+    real = torch.rand(B, 3, args.size, args.size, generator=g) * 2 - 1
+    state = torch.randn(B, state_dim, generator=g)
+    mg = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in pg.items()}
+    md = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in pd.items()}
+
+    def step(t):
+        for v in pg.values():
+            v.requires_grad_(True); v.grad = None
+        L, _ = O.generator_losses(pg, pd, pv, prev, state, real, spec)
+        sum(L.values()).backward()
+        with torch.no_grad():
+            for k in pg:
+                p, m, v = O.adam_step(pg[k].detach(), pg[k].grad, mg[k][0], mg[k][1], t, 1e-4, 0.0, 0.9)
+                pg[k] = p; mg[k] = (m, v)
+        for v in pd.values():
+            v.requires_grad_(True); v.grad = None
+        D = O.discriminator_losses(pg, pd, prev, state, real, spec)
+        sum(D.values()).backward()
+        with torch.no_grad():
+            for k in pd:
+                p, m, v = O.adam_step(pd[k].detach(), pd[k].grad, md[k][0], md[k][1], t, 4e-4, 0.0, 0.9)
+                pd[k] = p; md[k] = (m, v)
+
+    step(1)                                   # warm-up
+    t0 = time.time()
+    for i in range(args.cpu_steps):
+        step(2 + i)
+    dt = time.time() - t0
+    return dict(value=round(B * args.cpu_steps / dt, 3), unit="images/sec", cores=torch.get_num_threads(), kind="port",
+                sample="oracle/s2p_oracle.py G+D train step, batch %d of the same %dx%d workload, %d timed steps "
+                       "after 1 warm-up, torch fp32 on host cores" % (B, args.size, args.size, args.cpu_steps))
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE %d (launch with torch.distributed.run for N>1)" % (args.gpus, world),
+                  file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a HIP device: the S2P hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+
+    from s2p_amd import ops
+    from s2p_amd.options.train_options import TrainOptions
+    from s2p_amd.trainers.pix2pix_trainer import Pix2PixTrainer
+
+    opt = TrainOptions().parse(["--env_type", args.env_type, "--batchSize", str(args.batch), "--precision", args.precision,
+                                "--gpu_ids", str(local_rank), "--checkpoints_dir", "/tmp/s2p_bench_ckpt",
+                                "--crop_size", str(args.size)], quiet=True)
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        trainer = Pix2PixTrainer(opt)
+    dp = trainer.dp
+    dev = torch.device("cuda", local_rank)
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    data = dict(prev_image=(torch.rand(args.batch, 3, args.size, args.size, generator=g) * 2 - 1).to(dev),
+                image=(torch.rand(args.batch, 3, args.size, args.size, generator=g) * 2 - 1).to(dev),
+                state=torch.randn(args.batch, opt.state_dim, generator=g).to(dev))
+
+    def g_part():
+        trainer.optimizer_G.zero_grad()
+        g_losses, generated = trainer.pix2pix_model(data, mode="generator")
+        sum(g_losses.values()).mean().backward()
+        trainer.g_losses, trainer.generated = g_losses, generated
+
+    def d_part():
+        trainer.optimizer_D.zero_grad()
+        d_losses = trainer.pix2pix_model(data, mode="discriminator")
+        sum(d_losses.values()).mean().backward()
+        trainer.d_losses = d_losses
+
+    model = trainer.pix2pix_model
+    # The step as five segments; the two all-reduces stay outside the captured graphs (RCCL runs on its own stream).
+    segs = [g_part, lambda: dp.all_reduce_grads(model.netG.store), lambda: (trainer.optimizer_G.step(), d_part()),
+            lambda: dp.all_reduce_grads(model.netD.store), trainer.optimizer_D.step]
+    if world == 1:
+        segs = [lambda: (g_part(), trainer.optimizer_G.step(), d_part(), trainer.optimizer_D.step())]
+
+    def eager_step():
+        for s in segs:
+            s()
+
+    # warm-up (eager), then optional hipGraph capture of the compute segments
+    use_graph = not args.no_graph
+    for _ in range(max(1, min(args.warmup, 2))):
+        eager_step()
+    torch.cuda.synchronize()
+    graphs = None
+    if use_graph:
+        try:
+            graphs = []
+            side = torch.cuda.Stream()
+            for i, s in enumerate(segs):
+                if world > 1 and i in (1, 3):
+                    graphs.append(None)
+                    s()
+                    continue
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=side):
+                    s()
+                graphs.append(gr)
+            torch.cuda.synchronize()
+        except Exception as e:     # capture not possible: fall back to eager launches and say so
+            if rank == 0:
+                print("hipGraph capture failed (%s); running eager" % str(e).splitlines()[0], file=sys.stderr)
+            graphs = None
+            use_graph = False
+            torch.cuda.synchronize()
+
+    def step():
+        if graphs is None:
+            eager_step()
+        else:
+            for gr, s in zip(graphs, segs):
+                if gr is None:
+                    s()
+                else:
+                    gr.replay()
+
+    for _ in range(args.warmup):
+        step()
+    dp.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(); dp.barrier(); torch.cuda.synchronize()
+    elapsed = dp.max_over_ranks(time.perf_counter() - t0)
+    losses = {k: float(v) for k, v in trainer.get_latest_losses().items()}
+    if not all(v == v for v in losses.values()):
+        raise RuntimeError("NaN in losses: %s" % losses)
+
+    # ---- roofline leg: one instrumented eager step, events around every MFMA conv launch --------------------
+    roofline = None
+    if not args.no_roofline and rank == 0:
+        ops.PROFILE = []
+        eager_step()
+        torch.cuda.synchronize()
+        recs, ops.PROFILE = ops.PROFILE, None
+        tot_f = sum(r["flops"] for r in recs)
+        tot_ms = sum(r["events"][0].elapsed_time(r["events"][1]) for r in recs)
+        by_kind = {}
+        for r in recs:
+            k = by_kind.setdefault(r["kind"], [0.0, 0.0, 0])
+            k[0] += r["flops"]; k[1] += r["events"][0].elapsed_time(r["events"][1]); k[2] += 1
+        # dominant kernel: the implicit-GEMM conv family (conv_gather_kernel + wgrad_kernel), all launches of one step
+        ach = tot_f / (tot_ms * 1e-3) / 1e12
+        roofline = dict(bound="mfma", kernel="conv_gather_kernel<bf16>/wgrad_kernel<bf16> (all %d launches of one step)" % len(recs),
+                        achieved=round(ach, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                        traffic=None, algorithmic_gflop_per_step=round(tot_f / 1e9, 1), conv_ms_per_step=round(tot_ms, 3),
+                        avg_launch_us=round(tot_ms * 1e3 / max(len(recs), 1), 2),
+                        by_kind={k: dict(gflop=round(v[0] / 1e9, 1), ms=round(v[1], 3), launches=v[2],
+                                         tflops=round(v[0] / (v[1] * 1e-3) / 1e12, 2)) for k, v in by_kind.items()})
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, opt.state_dim)
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        out = {
+            "metric": "G+D train-step images/sec at 84x84 bs=64/GPU",
+            "value": round(args.batch * world * args.steps / elapsed, 2),
+            "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "configs[2]: full G+D train step (hinge GAN + feature matching + VGG19 perceptual "
+                                   "+ L1, Adam x2), %dx%d %s, netG=s2p, netD=multiscale(2)" % (args.size, args.size, args.env_type),
+                       "global_batch": args.batch * world, "per_gpu_batch": args.batch,
+                       "parallelism": "dp%d" % world, "hip_graph": bool(use_graph),
+                       "vgg_weights": "seeded stand-in (ImageNet weights unobtainable offline)"},
+            "roofline": roofline, "cpu_baseline": cpu, "losses": {k: round(v, 4) for k, v in losses.items()},
+        }
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -65,11 +65,14 @@ int s2p_conv2d_fwd(const s2p_conv_desc* d, const void* x, const void* w_fwd, con
 /* dx = d(loss)/dx.  w_bwd : packed [groups][Cin][KH*KW][Cout_pad] (the transpose of w_fwd).
  * dy has pitch y_pitch and channel count Cout (must itself satisfy the chunk multiple).
  * epi / aux as above (aux has the layout of dx); with S2P_EPI_MUL_ACTGRAD the result is
- * multiplied by aux_act'(aux) (aux = OUTPUT of the activation that produced x).
+ * multiplied by aux_act'(aux) (aux = OUTPUT of the activation that produced x); an optional
+ * aux2 (layout of dx) is added first: dx = (dgrad + aux2) * aux_act'(aux)  -- the gradient
+ * arriving at x from a second consumer (e.g. a feature-matching / perceptual loss tap).
  * Reflect-padded convs: dx is produced on the PADDED grid [N,H+2p,W+2p,x_pitch]; fold it
  * with s2p_reflect_pad_bwd.                                                             */
 int s2p_conv2d_dgrad(const s2p_conv_desc* d, const void* dy, const void* w_bwd,
-                     const void* aux, void* dx, int epi, int aux_act, float slope, void* stream);
+                     const void* aux, const void* aux2, void* dx, int epi, int aux_act, float slope,
+                     void* stream);
 /* dw (fp32) [groups][Cout][KH*KW][Cin_real] for transposed==0,
  *           [groups][Cin][KH*KW][Cout_real] for transposed==1  (= channels-last physical
  * layout of the torch parameter).  dw is ACCUMULATED into (caller zeroes it);
@@ -150,6 +153,10 @@ int s2p_hinge_loss(int dtype, const void* x, int64_t count, int mode, float scal
 /* torch.optim.Adam step on flat fp32 buffers; g is multiplied by grad_scale first.      */
 int s2p_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, int step, float grad_scale, void* stream);
+/* same update with the step counter in DEVICE memory (incremented on the device first), so the launch
+ * can be captured in a hipGraph and replayed                                             */
+int s2p_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                      float beta2, float eps, int* step_dev, float grad_scale, void* stream);
 /* one packing job: src fp32 [R][T][C] (channels-last master weight: R rows, T taps, C
  * channels) -> dst_fwd[r][t][c] (row length T*Cpad, zero pad c>=C)  and/or
  * dst_bwd[c][t][r_off + r] (row length T*Rrow; untouched elements must be pre-zeroed)    */

@@ -39,7 +39,7 @@ SIGNATURES = {
     "s2p_version": [],
     "s2p_last_error": [],
     "s2p_conv2d_fwd": [_DESC, _P, _P, _P, _P, _P, c_int, c_float, c_int, _P],
-    "s2p_conv2d_dgrad": [_DESC, _P, _P, _P, _P, c_int, c_int, c_float, _P],
+    "s2p_conv2d_dgrad": [_DESC, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P],
     "s2p_conv2d_wgrad": [_DESC, _P, _P, _P, c_int, c_int, c_int64, c_int, _P],
     "s2p_reflect_pad_bwd": [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P],
     "s2p_channel_sum": [c_int, _P, c_int64, c_int, c_int, _P, _P],
@@ -62,6 +62,7 @@ SIGNATURES = {
     "s2p_l1_loss": [c_int, _P, _P, c_int64, c_float, _P, _P, c_int, _P],
     "s2p_hinge_loss": [c_int, _P, c_int64, c_int, c_float, _P, _P, _P],
     "s2p_adam_step": [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int, c_float, _P],
+    "s2p_adam_step_dev": [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, _P, c_float, _P],
     "s2p_pack_weights": [_P, c_int, c_int, _P],
     "s2p_act_bwd": [c_int, _P, _P, c_int64, c_int, c_float, _P, _P],
     "s2p_scale": [c_int, _P, c_int64, _P, _P],

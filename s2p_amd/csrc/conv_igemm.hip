@@ -16,7 +16,7 @@
 #define MAX_TAPS 64
 
 struct GatherArgs {
-  const void* x; const void* w; const float* bias; const void* aux; void* y;
+  const void* x; const void* w; const float* bias; const void* aux; const void* aux2; void* y;
   int M, Hi, Wi, Qh, Qw;
   int Cin, x_pitch, x_gstride;
   int Cout, Cst, y_pitch, y_gstride;
@@ -240,6 +240,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_kernel(const GatherArgs a)
   constexpr int CPR = BCO / CE;
   T* yg = (T*)a.y + (size_t)g * a.y_gstride;
   const T* auxg = a.aux ? (const T*)a.aux + (size_t)g * a.y_gstride : nullptr;
+  const T* aux2g = a.aux2 ? (const T*)a.aux2 + (size_t)g * a.y_gstride : nullptr;
   for (int idx = tid; idx < BPIX * CPR; idx += 256) {
     int row = idx / CPR, ch = idx - row * CPR;
     int off = rowoff[row];
@@ -250,16 +251,22 @@ __global__ __launch_bounds__(256, 2) void conv_gather_kernel(const GatherArgs a)
     size_t go = (size_t)off * a.y_pitch + co0;
     bool full = co0 + CE <= a.Cst;
     if (a.epi != S2P_EPI_STORE) {
-      Chunk<T> x;
-      if (full) x.raw = *(const u32x4*)(auxg + go);
-      else {
+      Chunk<T> x, x2;
+      x2.raw = (u32x4){0u, 0u, 0u, 0u};
+      if (full) {
+        x.raw = *(const u32x4*)(auxg + go);
+        if (aux2g) x2.raw = *(const u32x4*)(aux2g + go);
+      } else {
         x.raw = (u32x4){0u, 0u, 0u, 0u};
-        for (int e = 0; e < CE; ++e) if (co0 + e < a.Cst) x.set(e, to_f32(auxg[go + e]));
+        for (int e = 0; e < CE; ++e) if (co0 + e < a.Cst) {
+          x.set(e, to_f32(auxg[go + e]));
+          if (aux2g) x2.set(e, to_f32(aux2g[go + e]));
+        }
       }
 #pragma unroll
       for (int e = 0; e < CE; ++e) {
         float v = c.get(e), xv = x.get(e);
-        v = (a.epi == S2P_EPI_ADD) ? v + xv : v * act_grad_from_out(xv, a.gact, a.gslope);
+        v = (a.epi == S2P_EPI_ADD) ? v + xv : (v + x2.get(e)) * act_grad_from_out(xv, a.gact, a.gslope);
         c.set(e, v);
       }
     }
@@ -297,10 +304,11 @@ struct Geo {
 
 // "gather" orientation: out(oy) = sum_k in(oy*stride + k - pad)   (conv fwd, convT dgrad)
 template <typename T>
-static int run_gather(const Geo& G, const void* x, const void* w, const float* bias, const void* aux, void* y,
+static int run_gather(const Geo& G, const void* x, const void* w, const float* bias, const void* aux,
+                      const void* aux2, void* y,
                       int act, float slope, int epi, int gact, float gslope, hipStream_t st) {
   GatherArgs a{};
-  a.x = x; a.w = w; a.bias = bias; a.aux = aux; a.y = y;
+  a.x = x; a.w = w; a.bias = bias; a.aux = aux; a.aux2 = aux2; a.y = y;
   a.Hi = G.Hi; a.Wi = G.Wi; a.Qh = G.Ho; a.Qw = G.Wo; a.M = G.N * G.Ho * G.Wo;
   a.Cin = G.Ci; a.x_pitch = G.xp; a.x_gstride = G.xg;
   a.Cout = G.Co; a.Cst = G.Cst; a.y_pitch = G.yp; a.y_gstride = G.yg;
@@ -316,13 +324,14 @@ static int run_gather(const Geo& G, const void* x, const void* w, const float* b
 // "scatter" orientation expressed per output phase: out(oy) = sum_k in((oy + pad - k)/stride)
 // (conv_transpose fwd, strided/unstrided conv dgrad)
 template <typename T>
-static int run_scatter(const Geo& G, const void* x, const void* w, const float* bias, const void* aux, void* y,
+static int run_scatter(const Geo& G, const void* x, const void* w, const float* bias, const void* aux,
+                       const void* aux2, void* y,
                        int act, float slope, int epi, int gact, float gslope, hipStream_t st) {
   const int s = G.stride;
   for (int py = 0; py < s; ++py)
     for (int px = 0; px < s; ++px) {
       GatherArgs a{};
-      a.x = x; a.w = w; a.bias = bias; a.aux = aux; a.y = y;
+      a.x = x; a.w = w; a.bias = bias; a.aux = aux; a.aux2 = aux2; a.y = y;
       a.Hi = G.Hi; a.Wi = G.Wi;
       a.Qh = (G.Ho - py + s - 1) / s; a.Qw = (G.Wo - px + s - 1) / s;
       if (a.Qh <= 0 || a.Qw <= 0) continue;
@@ -377,17 +386,17 @@ extern "C" int s2p_conv2d_fwd(const s2p_conv_desc* d, const void* x, const void*
         (long long)d->Cout * d->KH * d->KW * d->Cin, d->KH * d->KW * d->Cin};
   if (d->transposed) {
     if (d->reflect) S2P_FAIL(-1, "s2p_conv2d_fwd: reflect + transposed unsupported");
-    return d->dtype == S2P_F32 ? run_scatter<float>(G, x, w_fwd, bias, aux, y, act, slope, epi, 0, 0.f, st)
-                               : run_scatter<__bf16>(G, x, w_fwd, bias, aux, y, act, slope, epi, 0, 0.f, st);
+    return d->dtype == S2P_F32 ? run_scatter<float>(G, x, w_fwd, bias, aux, nullptr, y, act, slope, epi, 0, 0.f, st)
+                               : run_scatter<__bf16>(G, x, w_fwd, bias, aux, nullptr, y, act, slope, epi, 0, 0.f, st);
   }
-  return d->dtype == S2P_F32 ? run_gather<float>(G, x, w_fwd, bias, aux, y, act, slope, epi, 0, 0.f, st)
-                             : run_gather<__bf16>(G, x, w_fwd, bias, aux, y, act, slope, epi, 0, 0.f, st);
+  return d->dtype == S2P_F32 ? run_gather<float>(G, x, w_fwd, bias, aux, nullptr, y, act, slope, epi, 0, 0.f, st)
+                             : run_gather<__bf16>(G, x, w_fwd, bias, aux, nullptr, y, act, slope, epi, 0, 0.f, st);
 }
 
 // dgrad: gathered tensor = dy (grid Ho x Wo, channels Cout), produced tensor = dx (grid H x W, channels Cin).
 // With reflect padding the produced grid is the PADDED one, (H+2p) x (W+2p): fold it with s2p_reflect_pad_bwd.
 extern "C" int s2p_conv2d_dgrad(const s2p_conv_desc* d, const void* dy, const void* w_bwd, const void* aux,
-                                void* dx, int epi, int aux_act, float slope, void* stream) {
+                                const void* aux2, void* dx, int epi, int aux_act, float slope, void* stream) {
   int rc = check_desc(d, "s2p_conv2d_dgrad");
   if (rc) return rc;
   if (!dy || !w_bwd || !dx) S2P_FAIL(-1, "s2p_conv2d_dgrad: null pointer");
@@ -402,8 +411,8 @@ extern "C" int s2p_conv2d_dgrad(const s2p_conv_desc* d, const void* dy, const vo
         d->x_pitch, d->x_gstride, d->KH, d->KW, d->stride, pad, 0, d->groups,
         (long long)d->Cin * d->KH * d->KW * cout_pad, d->KH * d->KW * cout_pad};
   if (d->transposed)   // adjoint of a scatter is a gather
-    return d->dtype == S2P_F32 ? run_gather<float>(G, dy, w_bwd, nullptr, aux, dx, S2P_ACT_NONE, 0.f, epi, aux_act, slope, st)
-                               : run_gather<__bf16>(G, dy, w_bwd, nullptr, aux, dx, S2P_ACT_NONE, 0.f, epi, aux_act, slope, st);
-  return d->dtype == S2P_F32 ? run_scatter<float>(G, dy, w_bwd, nullptr, aux, dx, S2P_ACT_NONE, 0.f, epi, aux_act, slope, st)
-                             : run_scatter<__bf16>(G, dy, w_bwd, nullptr, aux, dx, S2P_ACT_NONE, 0.f, epi, aux_act, slope, st);
+    return d->dtype == S2P_F32 ? run_gather<float>(G, dy, w_bwd, nullptr, aux, aux2, dx, S2P_ACT_NONE, 0.f, epi, aux_act, slope, st)
+                               : run_gather<__bf16>(G, dy, w_bwd, nullptr, aux, aux2, dx, S2P_ACT_NONE, 0.f, epi, aux_act, slope, st);
+  return d->dtype == S2P_F32 ? run_scatter<float>(G, dy, w_bwd, nullptr, aux, aux2, dx, S2P_ACT_NONE, 0.f, epi, aux_act, slope, st)
+                             : run_scatter<__bf16>(G, dy, w_bwd, nullptr, aux, aux2, dx, S2P_ACT_NONE, 0.f, epi, aux_act, slope, st);
 }

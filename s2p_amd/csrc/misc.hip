@@ -311,10 +311,12 @@ template <typename T>
 __global__ void hinge_kernel(const T* x, long long count, int mode, float scale, float* loss, T* grad) {
   float s = 0.f;
   GRID_STRIDE(idx, count) {
-    float v = to_f32(x[idx]), l, gr;
-    if (mode == 0) { float t = 1.f + v; l = t > 0.f ? t : 0.f; gr = t > 0.f ? scale : 0.f; }
-    else if (mode == 1) { float t = 1.f - v; l = t > 0.f ? t : 0.f; gr = t > 0.f ? -scale : 0.f; }
-    else { l = -v; gr = -scale; }
+    const float v = to_f32(x[idx]);
+    const float sgn = mode == 0 ? 1.f : -1.f;           // d(1 + sgn*v)/dv
+    const float t = 1.f + sgn * v;
+    const bool on = t > 0.f;
+    const float l = mode == 2 ? -v : (on ? t : 0.f);
+    const float gr = mode == 2 ? -scale : (on ? sgn * scale : 0.f);
     s += l;
     if (grad) grad[idx] = from_f32<T>(gr);
   }
@@ -363,6 +365,37 @@ extern "C" int s2p_adam_step(float* p, const float* g, float* m, float* v, int64
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n4, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, (long long)n,
                      (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), grad_scale);
   S2P_CHECK_LAUNCH("adam_kernel");
+  return 0;
+}
+
+// graph-capturable variant: the step counter lives in device memory (a captured hipGraph replays the same
+// kernel arguments, so the bias corrections must be derived on the device).
+__global__ void adam_tick_kernel(int* step) { if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1; }
+__global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, long long n4, long long n, float lr,
+                                float beta1, float beta2, float eps, const int* step, float gscale) {
+  const int t = *step;
+  const float bc1 = 1.f - powf(beta1, (float)t), bc2 = 1.f - powf(beta2, (float)t);
+  const float lr_bc1 = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+  GRID_STRIDE(idx, n4) {
+    long long i = idx * 4;
+    long long e1 = i + 4 <= n ? 4 : n - i;
+    for (long long e = 0; e < e1; ++e) {
+      long long k = i + e;
+      float gg = g[k] * gscale;
+      float mm = beta1 * m[k] + (1.f - beta1) * gg;
+      float vv = beta2 * v[k] + (1.f - beta2) * gg * gg;
+      m[k] = mm; v[k] = vv;
+      p[k] -= lr_bc1 * mm / (sqrtf(vv) * inv_sqrt_bc2 + eps);
+    }
+  }
+}
+extern "C" int s2p_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int* step_dev, float grad_scale, void* stream) {
+  if (!p || !g || !m || !v || !step_dev) S2P_FAIL(-1, "s2p_adam_step_dev: bad argument");
+  long long n4 = (n + 3) / 4;
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_dev);
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for(n4, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, (long long)n,
+                     lr, beta1, beta2, eps, (const int*)step_dev, grad_scale);
+  S2P_CHECK_LAUNCH("adam_dev_kernel");
   return 0;
 }
 

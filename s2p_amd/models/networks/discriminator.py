@@ -1,0 +1,167 @@
+"""Multi-scale PatchGAN discriminator (`--netD multiscale`, sub-arch `n_layer`; SPADE lineage, README.md:73).
+
+Input: NHWC tensor [B,H,W,8] holding cat(prev_image, image) in channels 0..5 (SPEC.md D7).  Each scale is a stack
+of 4x4 convs (pad 2, strides 2,2,1 / last two stride 1), LeakyReLU(0.2), InstanceNorm on the middle layers; all
+intermediate features are returned for the feature-matching loss.  Explicit forward/backward over HIP launches;
+the feature-matching / hinge gradients of the intermediate features are folded into the dgrad epilogue (EPI_ADD).
+"""
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ..._lib import ACT_LRELU, ACT_NONE, EPI_ADD, EPI_MUL_ACTGRAD, EPI_STORE
+from ...ops import ConvGeom
+from .base_network import BaseNetwork
+from .generator import _Conv
+from .layers import ConvLayer
+
+LRELU = 0.2
+
+
+class NLayerDiscriminator(BaseNetwork):
+    @staticmethod
+    def modify_commandline_options(parser, is_train):
+        parser.add_argument("--n_layers_D", type=int, default=4, help="# layers in each discriminator")
+        return parser
+
+    def __init__(self, opt, input_nc=6):
+        super().__init__()
+        self.opt = opt
+        self.n_layers = opt.n_layers_D
+        self.input_nc = input_nc
+        nf = opt.ndf
+        self.model0 = _Conv(input_nc, nf, 4, bias=True)
+        self.chans = [nf]
+        for n in range(1, self.n_layers):
+            nf_prev, nf = nf, min(nf * 2, 512)
+            setattr(self, f"model{n}", _Conv(nf_prev, nf, 4, bias=False))      # InstanceNorm follows: no bias
+            self.chans.append(nf)
+        setattr(self, f"model{self.n_layers}", _Conv(nf, 1, 4, bias=True))
+        self.chans.append(1)
+
+    def _declare_packs(self, dt, store=None, prefix=""):
+        st = store if store is not None else self.store
+        self.lay = []
+        cin = self.input_nc
+        for n in range(self.n_layers + 1):
+            m = getattr(self, f"model{n}")
+            st.add(m.weight, "conv")
+            if m.bias is not None:
+                st.add(m.bias, "bias")
+            stride = 2 if n < self.n_layers - 1 else 1
+            pk = st.pack(f"{prefix}model{n}", [m.weight], [m.bias] if m.bias is not None else None, dtype=dt)
+            self.lay.append(ConvLayer(pk, ConvGeom(cin, self.chans[n], 4, stride, 2)))
+            cin = self.chans[n]
+
+    def fwd_nhwc(self, x):
+        """Returns (features list [f0..fn] NHWC, ctx)."""
+        nl = self.n_layers
+        f = self.lay[0].fwd(x, act=ACT_LRELU, slope=LRELU)
+        feats, saved = [f], [(x, None, None, f)]
+        for n in range(1, nl):
+            xin = f
+            c = self.lay[n].fwd(xin)
+            C = self.chans[n]
+            s = ops.in_stats(c, C)
+            f = ops.in_apply_fwd(c, C, s, act=ACT_LRELU, slope=LRELU)
+            feats.append(f)
+            saved.append((xin, c, s, f))
+        out = self.lay[nl].fwd(f)
+        feats.append(out)
+        saved.append((f, None, None, out))
+        return feats, saved
+
+    def bwd_nhwc(self, saved, grads, need_wgrad=True, need_dx=True):
+        """grads[j] = d(loss)/d(feature j) or None.  Returns d(loss)/dx (or None)."""
+        nl = self.n_layers
+        xin, _, _, out = saved[nl]
+        g = grads[nl]
+        if g is None:
+            raise RuntimeError("discriminator backward needs a gradient for the final logit map")
+        if need_wgrad:
+            self.lay[nl].wgrad(xin, g)
+        gprev = grads[nl - 1]
+        d = self.lay[nl].dgrad(g, xin.shape, aux=gprev, epi=EPI_ADD if gprev is not None else EPI_STORE)
+        for n in reversed(range(1, nl)):
+            xin, c, s, f = saved[n]
+            dc, _ = ops.in_bwd(d, c, self.chans[n], s, act=ACT_LRELU, slope=LRELU)
+            if need_wgrad:
+                self.lay[n].wgrad(xin, dc)
+            gprev = grads[n - 1]
+            if n == 1:      # xin = f0 = LeakyReLU(conv0): fold the tap gradient and the LeakyReLU mask into the epilogue
+                d = self.lay[n].dgrad(dc, xin.shape, aux=xin, aux2=gprev, epi=EPI_MUL_ACTGRAD, aux_act=ACT_LRELU,
+                                      slope=LRELU)
+            else:
+                d = self.lay[n].dgrad(dc, xin.shape, aux=gprev, epi=EPI_ADD if gprev is not None else EPI_STORE)
+        x, _, _, f0 = saved[0]
+        dpre = d
+        if need_wgrad:
+            self.lay[0].wgrad(x, dpre)
+        if need_dx:
+            return self.lay[0].dgrad(dpre, x.shape)
+        return None
+
+
+class MultiscaleDiscriminator(BaseNetwork):
+    @staticmethod
+    def modify_commandline_options(parser, is_train):
+        parser.add_argument("--netD_subarch", type=str, default="n_layer", help="architecture of each discriminator")
+        parser.add_argument("--num_D", type=int, default=2, help="number of discriminators (scales)")
+        opt, _ = parser.parse_known_args()
+        from . import find_network_using_name
+        subnetD = find_network_using_name(opt.netD_subarch, "discriminator")
+        subnetD.modify_commandline_options(parser, is_train)
+        return parser
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.num_D = opt.num_D
+        from . import find_network_using_name
+        sub = find_network_using_name(getattr(opt, "netD_subarch", "n_layer"), "discriminator")
+        for i in range(opt.num_D):
+            self.add_module("discriminator_%d" % i, sub(opt))
+
+    def subnets(self):
+        return [getattr(self, "discriminator_%d" % i) for i in range(self.num_D)]
+
+    def _declare_packs(self, dt):
+        for i, d in enumerate(self.subnets()):
+            d._declare_packs(dt, store=self.store, prefix=f"discriminator_{i}.")
+            d.compute_dtype = dt
+            d.finalized = True
+
+    def fwd_nhwc(self, x):
+        self._require_ready()
+        result, ctx = [], []
+        for i, d in enumerate(self.subnets()):
+            feats, saved = d.fwd_nhwc(x)
+            result.append(feats)
+            ctx.append((x, saved))
+            if i + 1 < self.num_D:
+                x = ops.avgpool_fwd(x)
+        return result, ctx
+
+    def bwd_nhwc(self, ctx, grads, need_wgrad=True, need_dx=True):
+        dx_next = None
+        for i in reversed(range(self.num_D)):
+            x, saved = ctx[i]
+            dx = self.subnets()[i].bwd_nhwc(saved, grads[i], need_wgrad=need_wgrad, need_dx=need_dx)
+            if need_dx:
+                if dx_next is not None:
+                    ops.avgpool_bwd(dx_next, tuple(x.shape), dx=dx, accumulate=True)
+                dx_next = dx
+        return dx_next
+
+    def forward(self, x):
+        """x: fp32 NCHW [B,6,H,W] = cat(prev_image, image).  Returns List[List[Tensor]] (per scale, per layer) of fp32
+        NCHW features, last entry = patch logits (inference/diagnostic API; the train step uses the fused loss nodes)."""
+        self._require_ready()
+        from ..._lib import chunk_elems
+        with torch.no_grad():
+            xd = ops.nchw_to_nhwc(x, self.compute_dtype, ops.pad_to(x.shape[1], chunk_elems(self.compute_dtype)))
+            res, _ = self.fwd_nhwc(xd)
+            out = []
+            for d, feats in zip(self.subnets(), res):
+                out.append([ops.nhwc_to_nchw(f, c) for f, c in zip(feats, d.chans)])
+        return out

@@ -1,0 +1,298 @@
+"""S2P generator, `--netG s2p` (README.md:33,59): (previous image, state) -> next image.
+
+State-conditioned SPADE/MAT ResNet encoder-decoder (SPEC.md; rebuttal.md:146-154 for the MAT block).  The whole
+network is ONE coarse autograd node whose forward/backward are explicit sequences of HIP launches; MI355X-first
+restructuring relative to a per-layer eager graph:
+  * the 12 MAT norms' image-conditioning branches depend only on `prev_image`, so their 12 `mlp_shared` convs run as
+    ONE conv 3->12*128 and their 24 gamma/beta convs as ONE grouped conv (12 groups x 128->2C) that fills all 256 CUs;
+  * the 12 state affines run as one fused linear 256 -> 12*2C;
+  * InstanceNorm + modulation + LeakyReLU is one stats pass + one elementwise pass (s2p_in_*), residual adds are
+    fused into the conv epilogue, weight gradients go straight into the flat grad buffer.
+"""
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ..._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, EPI_ADD, EPI_MUL_ACTGRAD, chunk_elems
+from ...ops import ConvGeom, pad_to
+from .base_network import BaseNetwork
+from .layers import ConvLayer
+
+LRELU = 0.2
+
+
+class _Linear(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(cout, cin))
+        self.bias = nn.Parameter(torch.zeros(cout))
+
+
+class _Conv(nn.Module):
+    def __init__(self, cin, cout, k, bias=True, transposed=False):
+        super().__init__()
+        shape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
+        self.weight = nn.Parameter(torch.zeros(shape))
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(cout))
+        else:
+            self.bias = None
+
+
+class StateMapping(nn.Module):
+    """PositionalEncoding(L) + n_mlp x (Linear + LeakyReLU 0.2)  (README.md:74-75 lineage)."""
+
+    def __init__(self, state_dim, L, w_dim, n_mlp):
+        super().__init__()
+        d = state_dim * (1 + 2 * L)
+        for i in range(n_mlp):
+            setattr(self, f"fc{i}", _Linear(d if i == 0 else w_dim, w_dim))
+
+
+class MATNorm(nn.Module):
+    """Parameters of one MAT norm: image branch (mlp_shared, mlp_gamma, mlp_beta) + state affine (fc_state)."""
+
+    def __init__(self, norm_nc, nhidden, w_dim):
+        super().__init__()
+        self.mlp_shared = _Conv(3, nhidden, 3)
+        self.mlp_gamma = _Conv(nhidden, norm_nc, 3)
+        self.mlp_beta = _Conv(nhidden, norm_nc, 3)
+        self.fc_state = _Linear(w_dim, 2 * norm_nc)
+
+
+class MATResnetBlock(nn.Module):
+    def __init__(self, c, nhidden, w_dim):
+        super().__init__()
+        self.norm_0 = MATNorm(c, nhidden, w_dim)
+        self.norm_1 = MATNorm(c, nhidden, w_dim)
+        self.conv_0 = _Conv(c, c, 3)
+        self.conv_1 = _Conv(c, c, 3)
+
+
+class S2PGenerator(BaseNetwork):
+    @staticmethod
+    def modify_commandline_options(parser, is_train):
+        parser.add_argument("--resnet_n_downsample", type=int, default=2, help="number of stride-2 stages in G")
+        parser.add_argument("--resnet_n_blocks", type=int, default=6, help="number of MAT residual blocks in G")
+        parser.add_argument("--mat_nhidden", type=int, default=128, help="hidden width of the MAT image branch")
+        parser.add_argument("--posenc_L", type=int, default=10, help="positional-encoding octaves for the state")
+        parser.add_argument("--n_mlp", type=int, default=4, help="layers of the state mapping MLP")
+        return parser
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.state_dim = opt.state_dim
+        self.ngf, self.n_down, self.n_blocks = opt.ngf, opt.resnet_n_downsample, opt.resnet_n_blocks
+        self.nhidden, self.w_dim, self.posenc_L, self.n_mlp = opt.mat_nhidden, opt.z_dim, opt.posenc_L, opt.n_mlp
+        ngf = self.ngf
+        self.state_map = StateMapping(self.state_dim, self.posenc_L, self.w_dim, self.n_mlp)
+        self.stem = _Conv(3, ngf, 7, bias=False)
+        c = ngf
+        for i in range(self.n_down):
+            setattr(self, f"down{i}", _Conv(c, 2 * c, 3, bias=False))
+            c *= 2
+        self.c_mid = c
+        self.blocks = nn.ModuleList([MATResnetBlock(c, self.nhidden, self.w_dim) for _ in range(self.n_blocks)])
+        for i in range(self.n_down):
+            setattr(self, f"up{i}", _Conv(c, c // 2, 3, bias=False, transposed=True))
+            c //= 2
+        self.out = _Conv(c, 3, 7, bias=True)
+
+    # ---- flat layout + packed operands ---------------------------------------------------------------------
+    def _norms(self):
+        return [n for b in self.blocks for n in (b.norm_0, b.norm_1)]
+
+    def _declare_packs(self, dt):
+        st, f32 = self.store, torch.float32
+        C, nh = self.c_mid, self.nhidden
+        norms = self._norms()
+        nn_ = len(norms)
+        L = {}
+        # state path (always fp32: 0.6 MFLOP/img, latency-bound; keeps the conditioning exact)
+        fcs = [getattr(self.state_map, f"fc{i}") for i in range(self.n_mlp)]
+        for i, fc in enumerate(fcs):
+            st.add(fc.weight, "linear"); st.add(fc.bias, "bias")
+            pk = st.pack(f"state_map.fc{i}", [fc.weight], [fc.bias], kind="linear", dtype=f32, need_bwd=i > 0)
+            L[f"fc{i}"] = ConvLayer(pk, ConvGeom(fc.weight.shape[1], fc.weight.shape[0], 1))
+        for n in norms:
+            st.add(n.fc_state.weight, "linear")
+        for n in norms:
+            st.add(n.fc_state.bias, "bias")
+        pk = st.pack("fc_state_all", [n.fc_state.weight for n in norms], [n.fc_state.bias for n in norms],
+                     kind="linear", dtype=f32)
+        L["fc_state"] = ConvLayer(pk, ConvGeom(self.w_dim, nn_ * 2 * C, 1))
+        # image-conditioning branch, batched over the 12 norms
+        for n in norms:
+            st.add(n.mlp_shared.weight, "conv")
+        for n in norms:
+            st.add(n.mlp_shared.bias, "bias")
+        pk = st.pack("mlp_shared_all", [n.mlp_shared.weight for n in norms], [n.mlp_shared.bias for n in norms],
+                     dtype=dt, need_bwd=False)
+        L["shared"] = ConvLayer(pk, ConvGeom(3, nn_ * nh, 3, 1, 1))
+        for n in norms:
+            st.add(n.mlp_gamma.weight, "conv"); st.add(n.mlp_beta.weight, "conv")
+        for n in norms:
+            st.add(n.mlp_gamma.bias, "bias"); st.add(n.mlp_beta.bias, "bias")
+        pk = st.pack("mlp_gb_all", [w for n in norms for w in (n.mlp_gamma.weight, n.mlp_beta.weight)],
+                     [b for n in norms for b in (n.mlp_gamma.bias, n.mlp_beta.bias)], groups=nn_, dtype=dt)
+        L["gb"] = ConvLayer(pk, ConvGeom(nh, 2 * C, 3, 1, 1, groups=nn_, x_gstride=nh, y_gstride=2 * C))
+        # trunk
+        st.add(self.stem.weight, "conv")
+        L["stem"] = ConvLayer(st.pack("stem", [self.stem.weight], dtype=dt, need_bwd=False),
+                              ConvGeom(3, self.ngf, 7, 1, 3, reflect=True))
+        c = self.ngf
+        for i in range(self.n_down):
+            d = getattr(self, f"down{i}")
+            st.add(d.weight, "conv")
+            L[f"down{i}"] = ConvLayer(st.pack(f"down{i}", [d.weight], dtype=dt), ConvGeom(c, 2 * c, 3, 2, 1))
+            c *= 2
+        for b, blk in enumerate(self.blocks):
+            for j, cv in enumerate((blk.conv_0, blk.conv_1)):
+                st.add(cv.weight, "conv"); st.add(cv.bias, "bias")
+                L[f"b{b}c{j}"] = ConvLayer(st.pack(f"blocks.{b}.conv_{j}", [cv.weight], [cv.bias], dtype=dt),
+                                           ConvGeom(c, c, 3, 1, 1))
+        for i in range(self.n_down):
+            u = getattr(self, f"up{i}")
+            st.add(u.weight, "convT")
+            L[f"up{i}"] = ConvLayer(st.pack(f"up{i}", [u.weight], kind="convT", dtype=dt),
+                                    ConvGeom(c, c // 2, 3, 2, 1, transposed=True, output_padding=1))
+            c //= 2
+        st.add(self.out.weight, "conv"); st.add(self.out.bias, "bias")
+        L["out"] = ConvLayer(st.pack("out", [self.out.weight], [self.out.bias], dtype=dt),
+                             ConvGeom(c, 3, 7, 1, 3, reflect=True))
+        self.lay = L
+
+    # ---- explicit forward / backward on NHWC tensors -------------------------------------------------------
+    def fwd_nhwc(self, img, state, save=True):
+        """img: NHWC compute-dtype [N,H,W,ce] (3 real channels), state fp32 [N,S].  Returns (out NHWC, ctx)."""
+        self._require_ready()
+        L, C, nh = self.lay, self.c_mid, self.nhidden
+        N, H, W, _ = img.shape
+        if H % (1 << self.n_down) or W % (1 << self.n_down):
+            raise ValueError(f"image size {H}x{W} must be a multiple of {1 << self.n_down}")
+        ctx = {}
+        # state path
+        pe_pitch = pad_to(self.state_dim * (1 + 2 * self.L_oct), 4)
+        h = ops.posenc(state.contiguous(), self.L_oct, pe_pitch).view(N, 1, 1, pe_pitch)
+        hs = [h]
+        for i in range(self.n_mlp):
+            h = L[f"fc{i}"].fwd(h, act=ACT_LRELU, slope=LRELU)
+            hs.append(h)
+        st_all = L["fc_state"].fwd(h).view(N, -1)                       # [N, 12*2C] fp32
+        # image conditioning
+        hq, wq = H >> self.n_down, W >> self.n_down
+        seg = ops.resize_nearest(img, hq, wq)
+        actv = L["shared"].fwd(seg, act=ACT_RELU)                       # [N,h,w,12*nh]
+        gb_all = L["gb"].fwd(actv)                                      # [N,h,w,12*2C]
+        # encoder
+        enc = []
+        x = L["stem"].fwd(img)
+        s = ops.in_stats(x, self.ngf)
+        a = ops.in_apply_fwd(x, self.ngf, s, act=ACT_RELU)
+        enc.append((img, x, s, a))
+        c = self.ngf
+        for i in range(self.n_down):
+            xin = a
+            x = L[f"down{i}"].fwd(xin)
+            c *= 2
+            s = ops.in_stats(x, c)
+            a = ops.in_apply_fwd(x, c, s, act=ACT_RELU)
+            enc.append((xin, x, s, a))
+        # MAT residual blocks
+        blocks = []
+        x = a
+        for b in range(self.n_blocks):
+            o0, o1 = (2 * b) * 2 * C, (2 * b + 1) * 2 * C
+            sA = ops.in_stats(x, C)
+            nA = ops.in_apply_fwd(x, C, sA, gb_all, o0, st_all, o0, ACT_LRELU, LRELU)
+            c0 = L[f"b{b}c0"].fwd(nA)
+            sB = ops.in_stats(c0, C)
+            nB = ops.in_apply_fwd(c0, C, sB, gb_all, o1, st_all, o1, ACT_LRELU, LRELU)
+            xn = L[f"b{b}c1"].fwd(nB, aux=x, epi=EPI_ADD)
+            blocks.append((x, sA, nA, c0, sB, nB))
+            x = xn
+        # decoder
+        dec = []
+        for i in range(self.n_down):
+            xin = x
+            u = L[f"up{i}"].fwd(xin)
+            c //= 2
+            s = ops.in_stats(u, c)
+            x = ops.in_apply_fwd(u, c, s, act=ACT_RELU)
+            dec.append((xin, u, s, x))
+        out = L["out"].fwd(x, act=ACT_TANH)
+        if save:
+            ctx.update(hs=hs, st_all=st_all, seg=seg, actv=actv, gb_all=gb_all, enc=enc, blocks=blocks, dec=dec,
+                       out=out, last=x)
+        return out, ctx
+
+    @property
+    def L_oct(self):
+        return self.posenc_L
+
+    def bwd_nhwc(self, ctx, d_out):
+        """Backward from d(loss)/d(out) (NHWC).  All parameter gradients are accumulated into the flat grad buffer."""
+        L, C, nh = self.lay, self.c_mid, self.nhidden
+        out = ctx["out"]
+        dpre = ops.act_bwd(d_out, out, ACT_TANH)
+        L["out"].wgrad(ctx["last"], dpre)
+        dx = L["out"].dgrad(dpre, ctx["last"].shape)
+        c = self.ngf
+        for i in reversed(range(self.n_down)):
+            xin, u, s, a = ctx["dec"][i]
+            cc = u.shape[3]
+            du, _ = ops.in_bwd(dx, u, cc, s, act=ACT_RELU)
+            L[f"up{i}"].wgrad(xin, du)
+            dx = L[f"up{i}"].dgrad(du, xin.shape)
+        gb_all, st_all = ctx["gb_all"], ctx["st_all"]
+        dgb_all = torch.empty_like(gb_all)
+        dst_all = torch.empty_like(st_all)
+        N = st_all.shape[0]
+        dst_v = dst_all.view(N, -1, 2, C)                               # [N, 12, {gamma,beta}, C]
+        for b in reversed(range(self.n_blocks)):
+            x, sA, nA, c0, sB, nB = ctx["blocks"][b]
+            o0, o1 = (2 * b) * 2 * C, (2 * b + 1) * 2 * C
+            L[f"b{b}c1"].wgrad(nB, dx)
+            d_nB = L[f"b{b}c1"].dgrad(dx, nB.shape)
+            d_c0, sums = ops.in_bwd(d_nB, c0, C, sB, gb_all, o1, st_all, o1, ACT_LRELU, LRELU, dgb_all, o1)
+            dst_v[:, 2 * b + 1].copy_(sums[:, :, 2:4].permute(0, 2, 1))
+            L[f"b{b}c0"].wgrad(nA, d_c0)
+            d_nA = L[f"b{b}c0"].dgrad(d_c0, nA.shape)
+            d_xb, sums = ops.in_bwd(d_nA, x, C, sA, gb_all, o0, st_all, o0, ACT_LRELU, LRELU, dgb_all, o0)
+            dst_v[:, 2 * b].copy_(sums[:, :, 2:4].permute(0, 2, 1))
+            dx = ops.add(dx, d_xb, out=d_xb)
+        # image-conditioning branch (batched)
+        actv, seg = ctx["actv"], ctx["seg"]
+        L["gb"].wgrad(actv, dgb_all)
+        d_actv = L["gb"].dgrad(dgb_all, actv.shape, aux=actv, epi=EPI_MUL_ACTGRAD, aux_act=ACT_RELU)
+        L["shared"].wgrad(seg, d_actv)
+        # state path
+        hs = ctx["hs"]
+        dstv = dst_all.view(N, 1, 1, -1)
+        L["fc_state"].wgrad(hs[-1], dstv)
+        dh = L["fc_state"].dgrad(dstv, hs[-1].shape)
+        for i in reversed(range(self.n_mlp)):
+            dpre = ops.act_bwd(dh, hs[i + 1], ACT_LRELU, LRELU)
+            L[f"fc{i}"].wgrad(hs[i], dpre)
+            if i > 0:
+                dh = L[f"fc{i}"].dgrad(dpre, hs[i].shape)
+        # encoder
+        for i in reversed(range(self.n_down)):
+            xin, x, s, a = ctx["enc"][i + 1]
+            dxe, _ = ops.in_bwd(dx, x, x.shape[3], s, act=ACT_RELU)
+            L[f"down{i}"].wgrad(xin, dxe)
+            dx = L[f"down{i}"].dgrad(dxe, xin.shape)
+        img, x, s, a = ctx["enc"][0]
+        dxe, _ = ops.in_bwd(dx, x, self.ngf, s, act=ACT_RELU)
+        L["stem"].wgrad(img, dxe)
+
+    # ---- public torch-style API --------------------------------------------------------------------------------
+    def forward(self, prev_image, state):
+        """prev_image: fp32 NCHW [N,3,H,W] in [-1,1]; state: fp32 [N,S] -> fp32 NCHW [N,3,H,W] (autograd-aware)."""
+        from ..autograd_nodes import generator_apply, nhwc_to_nchw_apply
+        return nhwc_to_nchw_apply(generator_apply(self, prev_image, state), 3)
+
+    def forward_nhwc(self, prev_image, state):
+        from ..autograd_nodes import generator_apply
+        return generator_apply(self, prev_image, state)

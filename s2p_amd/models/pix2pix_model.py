@@ -1,0 +1,164 @@
+"""Pix2PixModel-style wrapper (SPADE lineage, README.md:73): `forward(data, mode)` with
+modes generator / discriminator / inference, `create_optimizers`, `save` / load of
+`<checkpoints_dir>/<env_type>_<epoch>.pth` (README.md:19-26).
+
+data dict: {'prev_image': fp32 [N,3,H,W] in [-1,1], 'state': fp32 [N,S], 'image': fp32 [N,3,H,W]}.
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from . import networks
+from .autograd_nodes import d_losses_apply, g_losses_apply, generator_apply, nhwc_to_nchw_apply
+from .networks.loss import VGG19
+
+
+class FlatAdam:
+    """torch.optim-like facade over ParamStore's fused HIP Adam (one launch over the flat buffer)."""
+
+    def __init__(self, net, lr, betas, eps=1e-8):
+        self.net, self.lr, self.betas, self.eps = net, lr, betas, eps
+        self.grad_scale = 1.0
+        self.param_groups = [dict(lr=lr)]
+
+    def zero_grad(self, set_to_none=False):
+        self.net.store.zero_grad()
+
+    def step(self):
+        self.net.store.adam_step(self.param_groups[0]["lr"], self.betas[0], self.betas[1], self.eps, self.grad_scale)
+
+    def state_dict(self):
+        return dict(lr=self.param_groups[0]["lr"], **self.net.store.optimizer_state())
+
+    def load_state_dict(self, st):
+        self.param_groups[0]["lr"] = st.get("lr", self.lr)
+        self.net.store.load_optimizer_state(st)
+
+
+class Pix2PixModel(nn.Module):
+    @staticmethod
+    def modify_commandline_options(parser, is_train):
+        return parser
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        if not opt.gpu_ids:
+            raise RuntimeError("S2P runs on a HIP device only: --gpu_ids -1 (CPU) is not supported; there is no CPU "
+                               "fallback in the product path (tests/ use oracle/ for CPU references)")
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible (torch.cuda.is_available() is False): the S2P hot path cannot run")
+        self.device = torch.device("cuda", opt.gpu_ids[0])
+        torch.cuda.set_device(self.device)
+        self.compute_dtype = torch.bfloat16 if opt.precision == "bf16" else torch.float32
+        self.assume_unit_loss_grad = True       # trainers call sum(losses).backward(): upstream grads are exactly 1
+        self.netG, self.netD, self.vgg = self.initialize_networks(opt)
+
+    # ---- construction / checkpoint I/O ---------------------------------------------------------------------
+    def ckpt_path(self, epoch):
+        return os.path.join(self.opt.checkpoints_dir, "%s_%s.pth" % (self.opt.env_type, epoch))
+
+    def initialize_networks(self, opt):
+        netG = networks.define_G(opt)
+        netD = networks.define_D(opt) if opt.isTrain else None
+        vgg = None
+        ckpt = None
+        want = (not opt.isTrain) or getattr(opt, "continue_train", False)
+        if want:
+            path = self.ckpt_path(opt.which_epoch)
+            if os.path.exists(path):
+                ckpt = torch.load(path, map_location="cpu")
+            elif not getattr(opt, "random_init", False) and not opt.isTrain:
+                raise FileNotFoundError("%s not found (README: put <env_type>_<epoch>.pth under --checkpoints_dir), "
+                                        "or pass --random_init" % path)
+        if ckpt is not None:
+            netG.load_state_dict(ckpt["netG"] if "netG" in ckpt else ckpt)
+            if netD is not None and "netD" in ckpt:
+                netD.load_state_dict(ckpt["netD"])
+        netG.finalize(self.device, self.compute_dtype)
+        if netD is not None:
+            netD.finalize(self.device, self.compute_dtype)
+            if not opt.no_vgg_loss:
+                vgg = VGG19()
+                if opt.vgg_weights:
+                    vgg.load_torchvision(opt.vgg_weights)
+                else:
+                    vgg.init_standin()
+                vgg.finalize(self.device, self.compute_dtype)
+        self._resume = ckpt
+        return netG, netD, vgg
+
+    def save(self, epoch):
+        os.makedirs(self.opt.checkpoints_dir, exist_ok=True)
+        ck = dict(netG=self.netG.export_state_dict(), epoch=epoch, env_type=self.opt.env_type,
+                  state_dim=self.opt.state_dim)
+        if self.netD is not None:
+            ck["netD"] = self.netD.export_state_dict()
+        opts = getattr(self, "_optimizers", None)
+        if opts:
+            ck["optG"], ck["optD"] = opts[0].state_dict(), opts[1].state_dict()
+        torch.save(ck, self.ckpt_path(epoch))
+
+    def create_optimizers(self, opt):
+        if opt.no_TTUR:
+            beta1, beta2 = opt.beta1, opt.beta2
+            G_lr, D_lr = opt.lr, opt.lr
+        else:
+            beta1, beta2 = 0.0, 0.9
+            G_lr, D_lr = opt.lr / 2, opt.lr * 2
+        optG = FlatAdam(self.netG, G_lr, (beta1, beta2))
+        optD = FlatAdam(self.netD, D_lr, (beta1, beta2))
+        if self._resume is not None and "optG" in self._resume:
+            optG.load_state_dict(self._resume["optG"])
+            optD.load_state_dict(self._resume["optD"])
+        self._optimizers = (optG, optD)
+        return optG, optD
+
+    # ---- forward ---------------------------------------------------------------------------------------------
+    def preprocess_input(self, data):
+        dev = self.device
+        prev = data["prev_image"].to(dev, dtype=torch.float32, non_blocking=True).contiguous()
+        state = data["state"].to(dev, dtype=torch.float32, non_blocking=True).contiguous()
+        real = data.get("image")
+        if real is not None:
+            real = real.to(dev, dtype=torch.float32, non_blocking=True).contiguous()
+        return prev, state, real
+
+    def forward(self, data, mode):
+        prev, state, real = self.preprocess_input(data)
+        if mode == "generator":
+            g_loss, generated = self.compute_generator_loss(prev, state, real)
+            return g_loss, generated
+        elif mode == "discriminator":
+            return self.compute_discriminator_loss(prev, state, real)
+        elif mode == "inference":
+            with torch.no_grad():
+                return self.netG(prev, state)
+        raise ValueError("|mode| is invalid")
+
+    def compute_generator_loss(self, prev, state, real):
+        fake = generator_apply(self.netG, prev, state)                 # NHWC compute dtype, autograd node
+        L = g_losses_apply(self, fake, prev, real)
+        G_losses = {"GAN": L[0]}
+        if not self.opt.no_ganFeat_loss:
+            G_losses["GAN_Feat"] = L[1]
+        if not self.opt.no_vgg_loss:
+            G_losses["VGG"] = L[2]
+        if self.opt.lambda_l1 > 0:
+            G_losses["L1"] = L[3]
+        self._last_fake = fake.detach()
+        return G_losses, fake
+
+    def compute_discriminator_loss(self, prev, state, real, reuse_fake=False):
+        if reuse_fake and getattr(self, "_last_fake", None) is not None:
+            fake = self._last_fake
+        else:
+            with torch.no_grad():
+                fake = generator_apply(self.netG, prev, state)
+        L = d_losses_apply(self, fake, prev, real)
+        return {"D_Fake": L[0], "D_real": L[1]}
+
+    def generated_to_nchw(self, fake_nhwc):
+        with torch.no_grad():
+            return nhwc_to_nchw_apply(fake_nhwc.detach(), 3)

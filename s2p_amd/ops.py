@@ -14,6 +14,30 @@ from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, EPI_ADD, EPI_MUL_ACT
 
 IN_EPS = 1e-5
 
+# Optional in-situ profiler used by bench.py's roofline leg: when PROFILE is a list, every MFMA conv launch is
+# bracketed by two events on the launch stream and logged with its algorithmic FLOPs (2*MACs, un-padded channels).
+PROFILE = None
+
+
+class _Prof:
+    def __init__(self, kind, geom, N, H, W, dtype):
+        self.on = PROFILE is not None
+        if self.on:
+            Ho, Wo = geom.out_hw(H, W)
+            pix = N * H * W if geom.transposed else N * Ho * Wo
+            self.rec = dict(kind=kind, flops=2.0 * pix * geom.cin * geom.cout * geom.k * geom.k * geom.groups,
+                            shape=(N, H, W, geom.cin, geom.cout, geom.k, geom.stride, geom.groups, int(geom.transposed)),
+                            dtype=str(dtype))
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def done(self):
+        if self.on:
+            self.e1.record()
+            self.rec["events"] = (self.e0, self.e1)
+            PROFILE.append(self.rec)
+
 
 def pad_to(c, ce):
     return (c + ce - 1) // ce * ce
@@ -53,12 +77,14 @@ def conv_fwd(geom, x, w_fwd, bias, cin_pad, y_pitch=None, act=ACT_NONE, slope=0.
         y_pitch = pad_to(geom.cout * geom.groups if geom.groups > 1 else geom.cout, ce)
     y = out if out is not None else torch.empty((N, Ho, Wo, y_pitch), dtype=x.dtype, device=x.device)
     d = geom.desc(x.dtype, N, H, W, cin_pad, xp, y_pitch)
+    pr = _Prof("fwd", geom, N, H, W, x.dtype)
     check(lib().s2p_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(w_fwd), ptr(bias), ptr(aux), ptr(y), act, slope, epi,
                                stream()), "s2p_conv2d_fwd")
+    pr.done()
     return y
 
 
-def conv_dgrad(geom, dy, w_bwd, x_shape, cin_pad, aux=None, epi=EPI_STORE, aux_act=ACT_NONE, slope=0.2):
+def conv_dgrad(geom, dy, w_bwd, x_shape, cin_pad, aux=None, epi=EPI_STORE, aux_act=ACT_NONE, slope=0.2, aux2=None):
     """dx of the conv (cudnn_convolution_backward_input equivalent).  For reflect-padded convs the padded-grid
     gradient is folded back (adjoint of F.pad(mode='reflect'))."""
     N, H, W, xp = x_shape
@@ -66,19 +92,27 @@ def conv_dgrad(geom, dy, w_bwd, x_shape, cin_pad, aux=None, epi=EPI_STORE, aux_a
     if geom.reflect:
         p = geom.pad
         dxp = torch.empty((N, H + 2 * p, W + 2 * p, xp), dtype=dy.dtype, device=dy.device)
-        check(lib().s2p_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(w_bwd), None, ptr(dxp), EPI_STORE, ACT_NONE, 0.0,
+        pr = _Prof("dgrad", geom, N, H, W, dy.dtype)
+        check(lib().s2p_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(w_bwd), None, None, ptr(dxp), EPI_STORE, ACT_NONE, 0.0,
                                      stream()), "s2p_conv2d_dgrad")
+        pr.done()
         dx = torch.empty((N, H, W, xp), dtype=dy.dtype, device=dy.device)
         check(lib().s2p_reflect_pad_bwd(dtype_id(dy.dtype), ptr(dxp), N, H, W, xp, p, ptr(dx), stream()),
               "s2p_reflect_pad_bwd")
+        if aux2 is not None:
+            dx = add(dx, aux2, out=dx)
         if epi == EPI_MUL_ACTGRAD:
             dx = act_bwd(dx, aux, aux_act, slope)
+        elif epi == EPI_ADD:
+            dx = add(dx, aux, out=dx)
         return dx
     dx = torch.empty((N, H, W, xp), dtype=dy.dtype, device=dy.device)
     if xp != cin_pad * geom.groups:
         dx.zero_()
-    check(lib().s2p_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(w_bwd), ptr(aux), ptr(dx), epi, aux_act, slope,
+    pr = _Prof("dgrad", geom, N, H, W, dy.dtype)
+    check(lib().s2p_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(w_bwd), ptr(aux), ptr(aux2), ptr(dx), epi, aux_act, slope,
                                  stream()), "s2p_conv2d_dgrad")
+    pr.done()
     return dx
 
 
@@ -86,8 +120,10 @@ def conv_wgrad(geom, x, dy, dw, cin_pad, cin_real, cout_real, dw_gstride=0, spli
     """dw += wgrad (cudnn_convolution_backward_weight equivalent); dw is an fp32 view in channels-last layout."""
     N, H, W, xp = x.shape
     d = geom.desc(x.dtype, N, H, W, cin_pad, xp, dy.shape[3])
+    pr = _Prof("wgrad", geom, N, H, W, x.dtype)
     check(lib().s2p_conv2d_wgrad(ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), cin_real, cout_real, dw_gstride, splitk,
                                  stream()), "s2p_conv2d_wgrad")
+    pr.done()
 
 
 def channel_sum(dy, C, db):
@@ -256,3 +292,9 @@ def copy_channels(src, src_off, dst, dst_off, C, accumulate=False, src_rows=None
     check(lib().s2p_copy_channels(dtype_id(src.dtype), sptr, sp, src_off, dptr, dp, dst_off, C, n_img * ppi,
                                   int(accumulate), stream()), "s2p_copy_channels")
     return dst
+
+
+def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, step_dev, grad_scale=1.0):
+    """Graph-capturable Adam: `step_dev` is an int32 device tensor incremented on the device."""
+    check(lib().s2p_adam_step_dev(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, ptr(step_dev),
+                                  grad_scale, stream()), "s2p_adam_step_dev")

@@ -1,0 +1,42 @@
+"""train.py -- S2P training (README.md:59):
+    python train.py --dataroot=./datasets/cheetah.hdf5 --env_type=cheetah --netG=s2p --batchSize=16 --gpu_ids=0
+Multi-GPU: one process per GPU,  python -m torch.distributed.run --nproc-per-node 8 train.py ...  (RCCL all-reduce of
+the flat G/D gradient buffers)."""
+import time
+
+import torch
+
+from s2p_amd.data import create_dataloader
+from s2p_amd.options.train_options import TrainOptions
+from s2p_amd.trainers.pix2pix_trainer import Pix2PixTrainer
+
+
+def main(args=None):
+    opt = TrainOptions().parse(args, save=True)
+    trainer = Pix2PixTrainer(opt)
+    dl = create_dataloader(opt, trainer.dp.rank, trainer.dp.world_size)
+    total_epochs = opt.niter + opt.niter_decay
+    it = 0
+    for epoch in range(1, total_epochs + 1):
+        if hasattr(dl.sampler, "set_epoch"):
+            dl.sampler.set_epoch(epoch)
+        t0 = time.time()
+        for i, data in enumerate(dl):
+            it += 1
+            if i % opt.D_steps_per_G == 0:
+                trainer.run_generator_one_step(data)
+            trainer.run_discriminator_one_step(data)
+            if it % opt.print_freq == 0 and trainer.dp.rank == 0:
+                losses = {k: float(v) for k, v in trainer.get_latest_losses().items()}
+                print("(epoch %d, iters %d) " % (epoch, it) + " ".join("%s: %.3f" % kv for kv in losses.items()))
+        trainer.update_learning_rate(epoch)
+        if trainer.dp.rank == 0:
+            print("End of epoch %d / %d \t Time Taken: %d sec" % (epoch, total_epochs, time.time() - t0))
+        if epoch % opt.save_epoch_freq == 0 or epoch == total_epochs:
+            trainer.save("latest")
+            trainer.save(epoch)
+    torch.cuda.synchronize()
+
+
+if __name__ == "__main__":
+    main()
