@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--precision", type=str, default="bf16")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -51,7 +51,13 @@ def cpu_baseline(args, state_dim):
     """Oracle G+D train step (losses, both backward passes, both Adam updates) on the host cores, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import s2p_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    ncpu = max(1, min(ncpu, 16))          # the GPU box gives each GPU a 16-core share; more threads only thrash
+    torch.set_num_threads(ncpu)
+    print("[bench] cpu_baseline: oracle train step on %d host threads ..." % ncpu, file=sys.stderr, flush=True)
     spec = O.Spec(state_dim=state_dim)
     pg = O.init_params(O.generator_param_shapes(spec), 1)
     pd = O.init_params(O.discriminator_param_shapes(spec), 2)
@@ -83,9 +89,11 @@ def cpu_baseline(args, state_dim):
                 pd[k] = p; md[k] = (m, v)
 
     step(1)                                   # warm-up
+    print("[bench] cpu_baseline: warm-up step done", file=sys.stderr, flush=True)
     t0 = time.time()
     for i in range(args.cpu_steps):
         step(2 + i)
+        print("[bench] cpu_baseline: timed step %d done" % (i + 1), file=sys.stderr, flush=True)
     dt = time.time() - t0
     return dict(value=round(B * args.cpu_steps / dt, 3), unit="images/sec", cores=torch.get_num_threads(), kind="port",
                 sample="oracle/s2p_oracle.py G+D train step, batch %d of the same %dx%d workload, %d timed steps "
@@ -190,7 +198,8 @@ def main():
         step()
     torch.cuda.synchronize(); dp.barrier(); torch.cuda.synchronize()
     elapsed = dp.max_over_ranks(time.perf_counter() - t0)
-    losses = {k: float(v) for k, v in trainer.get_latest_losses().items()}
+    losses = {k: float(v.detach()) for k, v in trainer.get_latest_losses().items()}
+    print("[bench] timed region done: %.3f ms/step" % (elapsed / args.steps * 1e3), file=sys.stderr, flush=True)
     if not all(v == v for v in losses.values()):
         raise RuntimeError("NaN in losses: %s" % losses)
 
@@ -201,6 +210,7 @@ def main():
         eager_step()
         torch.cuda.synchronize()
         recs, ops.PROFILE = ops.PROFILE, None
+        print("[bench] roofline leg done (%d conv launches)" % len(recs), file=sys.stderr, flush=True)
         tot_f = sum(r["flops"] for r in recs)
         tot_ms = sum(r["events"][0].elapsed_time(r["events"][1]) for r in recs)
         by_kind = {}

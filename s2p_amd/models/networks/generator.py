@@ -290,9 +290,11 @@ class S2PGenerator(BaseNetwork):
     # ---- public torch-style API --------------------------------------------------------------------------------
     def forward(self, prev_image, state):
         """prev_image: fp32 NCHW [N,3,H,W] in [-1,1]; state: fp32 [N,S] -> fp32 NCHW [N,3,H,W] (autograd-aware)."""
+        self._require_ready()
         from ..autograd_nodes import generator_apply, nhwc_to_nchw_apply
         return nhwc_to_nchw_apply(generator_apply(self, prev_image, state), 3)
 
     def forward_nhwc(self, prev_image, state):
+        self._require_ready()
         from ..autograd_nodes import generator_apply
         return generator_apply(self, prev_image, state)

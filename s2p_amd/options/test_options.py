@@ -2,6 +2,7 @@ from .base_options import BaseOptions
 
 
 class TestOptions(BaseOptions):
+    __test__ = False      # not a pytest test class
     def initialize(self, parser):
         BaseOptions.initialize(self, parser)
         parser.add_argument("--results_dir", type=str, default="./results/", help="saves results here.")

@@ -1,0 +1,153 @@
+"""CPU: host-side logic of the product package -- plugin lookup, options, checkpoint naming, dataset, flat parameter
+layout, C-ABI exports -- and that the product path refuses to run without a HIP device (no CPU fallback)."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import s2p_oracle as O
+from s2p_amd import _lib, ops
+from s2p_amd.models import networks
+from s2p_amd.options.test_options import TestOptions
+from s2p_amd.options.train_options import TrainOptions
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_library_loads_and_exports_every_declared_symbol():
+    L = _lib.lib()
+    assert L.s2p_version() >= 100
+    header = open(os.path.join(ROOT, "include", "s2p_hip.h")).read()
+    declared = set(re.findall(r"\b(s2p_[a-z0-9_]+)\s*\(", header))
+    declared -= {"s2p_conv_desc", "s2p_pack_job"}
+    assert len(declared) >= 25
+    for name in sorted(declared):
+        assert hasattr(L, name), "libs2p_hip.so does not export %s" % name
+    assert declared == set(_lib.SIGNATURES.keys())
+
+
+def test_struct_layouts_match_header():
+    import ctypes
+    assert ctypes.sizeof(_lib.ConvDesc) == 19 * 4
+    assert ctypes.sizeof(_lib.PackJob) == 56      # 3 pointers + 7 int32, padded to 8-byte alignment (same in C)
+
+
+def test_netG_s2p_plugin_lookup_and_state_dict_contract():
+    cls = networks.find_network_using_name("s2p", "generator")
+    assert cls.__name__ == "S2PGenerator"
+    assert networks.find_network_using_name("multiscale", "discriminator").__name__ == "MultiscaleDiscriminator"
+    with pytest.raises(ValueError):
+        networks.find_network_using_name("nope", "generator")
+    opt = TrainOptions().parse(["--env_type", "walker", "--gpu_ids", "0"], quiet=True)
+    assert opt.state_dim == 24 and opt.netG == "s2p" and opt.gpu_ids == [0]
+    netG = networks.define_G(opt)
+    shapes = O.generator_param_shapes(O.Spec(state_dim=24))
+    sd = netG.state_dict()
+    assert list(sd.keys()).sort() == list(shapes.keys()).sort()
+    for k, shp in shapes.items():
+        assert tuple(sd[k].shape) == tuple(shp), k
+    netD = networks.define_D(opt)
+    dshapes = O.discriminator_param_shapes(O.Spec())
+    assert {k: tuple(v.shape) for k, v in netD.state_dict().items()} == {k: tuple(v) for k, v in dshapes.items()}
+    # SPADE-style init: xavier-normal(0.02) weights, zero biases
+    assert float(sd["out.bias"].abs().max()) == 0.0 and 0 < float(sd["stem.weight"].std()) < 0.01
+
+
+def test_readme_command_lines_parse():
+    o = TestOptions().parse("--env_type=cheetah --dataroot=./datasets --netG=s2p --start_idx=0 --seq_len=5 --gpu_ids=0".split(), quiet=True)
+    assert (o.env_type, o.netG, o.start_idx, o.seq_len, o.gpu_ids, o.state_dim) == ("cheetah", "s2p", 0, 5, [0], 17)
+    t = TrainOptions().parse("--dataroot=./datasets/cheetah.hdf5 --env_type=cheetah --netG=s2p --batchSize=16 --gpu_ids=0".split(), quiet=True)
+    assert t.batchSize == 16 and t.isTrain and t.lambda_feat == 10.0 and t.num_D == 2 and t.n_layers_D == 4
+
+
+def test_no_cpu_fallback():
+    from s2p_amd.models.pix2pix_model import Pix2PixModel
+    o = TestOptions().parse(["--gpu_ids", "-1", "--random_init"], quiet=True)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        Pix2PixModel(o)
+    if not torch.cuda.is_available():
+        o2 = TestOptions().parse(["--gpu_ids", "0", "--random_init"], quiet=True)
+        with pytest.raises(RuntimeError, match="HIP"):
+            Pix2PixModel(o2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.avgpool_fwd(torch.zeros(1, 4, 4, 4))
+    opt = TrainOptions().parse(["--gpu_ids", "0"], quiet=True)
+    netG = networks.define_G(opt)
+    with pytest.raises(RuntimeError, match="finalize|HIP"):
+        netG(torch.zeros(1, 3, 84, 84), torch.zeros(1, 17))
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        netG.finalize(torch.device("cpu"), torch.float32)
+    # the product package never imports the oracle
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "s2p_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                assert "s2p_oracle" not in open(os.path.join(dirpath, f)).read(), f
+
+
+def test_flat_param_store_layout_on_cpu():
+    """Flat master/grad buffers: parameters become channels-last views; fused packs are contiguous runs."""
+    opt = TrainOptions().parse(["--gpu_ids", "0"], quiet=True)
+    netG = networks.define_G(opt)
+    before = {k: v.detach().clone() for k, v in netG.state_dict().items()}
+    netG._declare_packs(torch.bfloat16)
+    st = netG.store
+    st.finalize(torch.device("cpu"))            # layout only: packing itself is a HIP launch
+    assert st.numel == sum(v.numel() for v in before.values())
+    for k, v in netG.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    w = netG.blocks[0].conv_0.weight
+    assert w.shape == (256, 256, 3, 3) and w.stride() == (9 * 256, 1, 3 * 256, 256)      # physically [Co][kh][kw][Ci]
+    assert w.grad is not None and w.grad.data_ptr() >= st.grad.data_ptr()
+    gb = netG.lay["gb"].pk
+    assert gb.groups == 12 and gb.R == 512 and gb.fwd.shape == (12, 512, 9, 128) and gb.bwd.shape == (12, 128, 9, 512)
+    assert gb.gw.numel() == 12 * 512 * 9 * 128 and gb.bias.numel() == 12 * 512
+    sh = netG.lay["shared"].pk
+    assert sh.fwd.shape == (1, 12 * 128, 9, 8) and sh.bwd is None
+    up = netG.lay["up0"].pk
+    assert up.kind == "convT" and up.w_fwd is up.bwd and up.w_fwd.shape == (1, 128, 9, 256)
+    # writing through the flat buffer is visible through the parameter views (what the fused Adam relies on)
+    st.master.add_(1.0)
+    assert torch.allclose(netG.out.bias, before["out.bias"] + 1.0)
+    ck = netG.export_state_dict()
+    assert all(v.is_contiguous() for v in ck.values())
+
+
+def test_dataset_and_checkpoint_naming(tmp_path):
+    from s2p_amd.data import S2PDataset, images_to_tensor, tensor_to_images
+    opt = TrainOptions().parse(["--dataroot", os.path.join(ROOT, "datasets"), "--env_type", "cheetah", "--gpu_ids", "0"], quiet=True)
+    ds = S2PDataset(opt)
+    assert len(ds) == 11
+    it = ds[3]
+    assert it["prev_image"].shape == (3, 84, 84) and it["state"].shape == (17,) and it["image"].shape == (3, 84, 84)
+    assert float(it["prev_image"].min()) >= -1 and float(it["prev_image"].max()) <= 1
+    frames, states = ds.sequence(0, 5)
+    assert frames.shape == (6, 3, 84, 84) and states.shape == (6, 17)
+    with pytest.raises(IndexError):
+        ds.sequence(8, 5)
+    u8 = (np.random.default_rng(0).integers(0, 256, (2, 84, 84, 3))).astype(np.uint8)
+    assert np.array_equal(tensor_to_images(images_to_tensor(u8)), u8)          # uint8 round trip is exact
+    # episode boundaries are never crossed
+    z = dict(np.load(os.path.join(ROOT, "datasets", "cheetah.npz")))
+    z["timeouts"][4] = True
+    np.savez(os.path.join(tmp_path, "cheetah.npz"), **z)
+    opt.dataroot = str(tmp_path)
+    assert 4 not in S2PDataset(opt).index
+    from s2p_amd.models.pix2pix_model import Pix2PixModel
+    m = Pix2PixModel.__new__(Pix2PixModel)
+    m.opt = opt
+    opt.checkpoints_dir = "./checkpoints"
+    assert m.ckpt_path(30) == "./checkpoints/cheetah_30.pth"                    # README.md:19-26
+
+
+def test_conv_geometry_matches_torch():
+    import torch.nn.functional as F
+    for (cin, cout, k, s, p, tr, op, H) in [(3, 8, 7, 1, 3, False, 0, 20), (8, 8, 3, 2, 1, False, 0, 21), (8, 4, 3, 2, 1, True, 1, 11),
+                                             (6, 8, 4, 2, 2, False, 0, 84), (8, 8, 4, 1, 2, False, 0, 12)]:
+        g = ops.ConvGeom(cin, cout, k, s, p, transposed=tr, output_padding=op)
+        x = torch.zeros(1, cin, H, H)
+        y = F.conv_transpose2d(x, torch.zeros(cin, cout, k, k), stride=s, padding=p, output_padding=op) if tr else \
+            F.conv2d(x, torch.zeros(cout, cin, k, k), stride=s, padding=p)
+        assert g.out_hw(H, H) == tuple(y.shape[2:])

@@ -17,7 +17,7 @@ def rel(a, b):
     return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-12))
 
 
-def grad_errors(named_hip, ref64, ref32=None):
+def grad_errors(named_hip, ref64, ref32=None, floor_frac=1e-3):
     """Per-parameter relative L2 error of the HIP gradients against the float64 oracle.  Gradients that are
     structurally zero (e.g. a conv bias in front of an InstanceNorm) are compared against a floor tied to the
     typical gradient magnitude instead of their own (rounding-noise) norm."""
@@ -27,7 +27,7 @@ def grad_errors(named_hip, ref64, ref32=None):
     for k, v in ref64.items():
         b = v.grad.double().flatten()
         a = named_hip[k].grad.detach().cpu().double().flatten()
-        floor = 1e-3 * typical * b.numel() ** 0.5
+        floor = floor_frac * typical * b.numel() ** 0.5
         e_hip = float((a - b).norm() / (b.norm() + floor))
         e_32 = None
         if ref32 is not None:
@@ -105,7 +105,7 @@ def test_generator_forward_backward(hip_device, tmp_path, precision, tol, gtol, 
     pg64 = to64(pg)
     (O.generator_forward(pg64, prev.double(), state.double(), spec) * r.double()).sum().backward()
     torch.cuda.synchronize()
-    errs = grad_errors(dict(model.netG.named_parameters()), pg64, pg)
+    errs = grad_errors(dict(model.netG.named_parameters()), pg64, pg, 1e-3 if precision == "fp32" else 5e-2)
     worst = sorted(errs.items(), key=lambda kv: -kv[1][0])[:5]
     print("worst grad rel-L2 errors (hip, fp32-oracle) vs fp64:", precision, worst)
     check_grads(errs, gtol, frac)
@@ -132,7 +132,7 @@ def test_train_step_losses_and_grads(hip_device, tmp_path, precision, tol, gtol)
     pg64, pd64, pv64 = to64(pg), {k: v.double() for k, v in pd.items()}, {k: v.double() for k, v in pv.items()}
     L64, _ = O.generator_losses(pg64, pd64, pv64, prev.double(), state.double(), real.double(), spec)
     sum(L64.values()).backward()
-    errs = grad_errors(dict(model.netG.named_parameters()), pg64, pg)
+    errs = grad_errors(dict(model.netG.named_parameters()), pg64, pg, 1e-3 if precision == "fp32" else 5e-2)
     print("G-step worst grad errors:", precision, sorted(errs.items(), key=lambda kv: -kv[1][0])[:5])
     check_grads(errs, gtol)
     # ---- discriminator step
@@ -153,7 +153,7 @@ def test_train_step_losses_and_grads(hip_device, tmp_path, precision, tol, gtol)
     D64 = O.discriminator_losses({k: v.detach().double() for k, v in pg.items()}, pd64, prev.double(), state.double(),
                                  real.double(), spec)
     sum(D64.values()).backward()
-    errs = grad_errors(dict(model.netD.named_parameters()), pd64, pd)
+    errs = grad_errors(dict(model.netD.named_parameters()), pd64, pd, 1e-3 if precision == "fp32" else 5e-2)
     print("D-step worst grad errors:", precision, sorted(errs.items(), key=lambda kv: -kv[1][0])[:5])
     check_grads(errs, gtol)
 
