@@ -12,6 +12,7 @@
 // padded to 80 B (conflict-free ds_read_b128); global->register->LDS staging, double buffered, one barrier
 // per K step; epilogue goes through LDS so every global store is a full 16-B chunk along the channel axis.
 #include "s2p_common.h"
+#include <stdlib.h>
 
 #define MAX_TAPS 64
 
@@ -27,12 +28,94 @@ struct GatherArgs {
   int reflect, act, epi, gact;
   float slope, gslope;
   int npix_tiles, nco_tiles;
+  int splitk, ksteps;          // generic fp32 path only: split-K over blockIdx.z with fp32 atomics into a zeroed y
+  unsigned x_bytes, w_bytes;   // fast path: buffer-descriptor sizes of the gathered tensor / packed weights (per group view)
   int tap[MAX_TAPS];   // (wt << 16) | ((dx & 0xff) << 8) | (dy & 0xff)
 };
 
 template <typename T> struct Mma;
 template <> struct Mma<__bf16> { static constexpr int BK = 32; };
 template <> struct Mma<float> { static constexpr int BK = 16; };
+
+template <typename T, int BCO, int BPIX, int TCO, int TPIX>
+__device__ __forceinline__ void conv_epilogue(const GatherArgs& a, f32x16 (&acc)[TCO][TPIX], char* smem, const int* rowoff,
+                                              int g, int co_base, int wco0, int wpix0, int r, int h, int tid) {
+  constexpr int CE = DT<T>::CE;
+  constexpr int ERS = BCO * (int)sizeof(T) + 16;
+  // ---- epilogue: bias + activation in registers, transpose through LDS, 16-B stores ----------
+  const float* bias = (a.bias && blockIdx.z == 0) ? a.bias + (size_t)g * a.Cout : nullptr;
+#pragma unroll
+  for (int i = 0; i < TCO; ++i) {
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      int col = wco0 + 32 * i + 8 * q4 + 4 * h;     // local co of element e=0
+      float bv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int co = co_base + col + e;
+        bv[e] = (bias && co < a.Cout) ? bias[co] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < TPIX; ++j) {
+        int prow_l = wpix0 + 32 * j + r;
+        char* dst = smem + prow_l * ERS + col * (int)sizeof(T);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_fwd(acc[i][j][4 * q4 + e] + bv[e], a.act, a.slope);
+        if constexpr (sizeof(T) == 2) {
+          bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+          *(bf16x4*)dst = o;
+        } else {
+          f32x4 o = {v[0], v[1], v[2], v[3]};
+          *(f32x4*)dst = o;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int CPR = BCO / CE;
+  T* yg = (T*)a.y + (size_t)g * a.y_gstride;
+  const T* auxg = a.aux ? (const T*)a.aux + (size_t)g * a.y_gstride : nullptr;
+  const T* aux2g = a.aux2 ? (const T*)a.aux2 + (size_t)g * a.y_gstride : nullptr;
+  for (int idx = tid; idx < BPIX * CPR; idx += 256) {
+    int row = idx / CPR, ch = idx - row * CPR;
+    int off = rowoff[row];
+    int co0 = co_base + ch * CE;
+    if (off < 0 || co0 >= a.Cst) continue;
+    Chunk<T> c;
+    c.raw = *(const u32x4*)(smem + row * ERS + ch * 16);
+    size_t go = (size_t)off * a.y_pitch + co0;
+    bool full = co0 + CE <= a.Cst;
+    if (a.epi != S2P_EPI_STORE) {
+      Chunk<T> x, x2;
+      x2.raw = (u32x4){0u, 0u, 0u, 0u};
+      if (full) {
+        x.raw = *(const u32x4*)(auxg + go);
+        if (aux2g) x2.raw = *(const u32x4*)(aux2g + go);
+      } else {
+        x.raw = (u32x4){0u, 0u, 0u, 0u};
+        for (int e = 0; e < CE; ++e) if (co0 + e < a.Cst) {
+          x.set(e, to_f32(auxg[go + e]));
+          if (aux2g) x2.set(e, to_f32(aux2g[go + e]));
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < CE; ++e) {
+        float v = c.get(e), xv = x.get(e);
+        v = (a.epi == S2P_EPI_ADD) ? v + xv : (v + x2.get(e)) * act_grad_from_out(xv, a.gact, a.gslope);
+        c.set(e, v);
+      }
+    }
+    if constexpr (sizeof(T) == 4) {
+      if (a.splitk > 1) {
+        for (int e = 0; e < CE; ++e) if (co0 + e < a.Cst) atomicAdd((float*)yg + go + e, c.get(e));
+        continue;
+      }
+    }
+    if (full) *(u32x4*)(yg + go) = c.raw;
+    else for (int e = 0; e < CE; ++e) if (co0 + e < a.Cst) yg[go + e] = from_f32<T>(c.get(e));
+  }
+}
 
 template <typename T, int BCO, int BPIX, int WCO, int WPIX>
 __global__ __launch_bounds__(256, 2) void conv_gather_kernel(const GatherArgs a) {
@@ -80,12 +163,12 @@ __global__ __launch_bounds__(256, 2) void conv_gather_kernel(const GatherArgs a)
   // ---- per-thread staging assignment -------------------------------------------------------
   const int jc = tid & 3;          // 16-byte chunk column inside the 64-byte K row
   const int r0 = tid >> 2;         // row 0..63 (+64*i)
+  const int nk_all = (a.Ktot + BK - 1) / BK;
+  const int kt0 = a.splitk > 1 ? (int)blockIdx.z * a.ksteps : 0;
+  const int kt1 = a.splitk > 1 ? (kt0 + a.ksteps < nk_all ? kt0 + a.ksteps : nk_all) : nk_all;
+  int kk = kt0 * BK + jc * CE;     // linear k of this thread's chunk
   int k_tap, k_c;                  // (tap, channel) of this thread's chunk, advanced by BK per step
-  {
-    int k = jc * CE;
-    k_tap = k / a.Cin; k_c = k - k_tap * a.Cin;
-  }
-  int kk = jc * CE;                // linear k of this thread's chunk
+  k_tap = kk / a.Cin; k_c = kk - k_tap * a.Cin;
   // pixel rows handled by this thread
   int p_py[NLP], p_px[NLP], p_base[NLP];
   bool p_ok[NLP];
@@ -101,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_kernel(const GatherArgs a)
   const T* wg = (const T*)a.w + (size_t)g * a.w_gstride;
 
   u32x4 regW[NLW], regP[NLP];
-  const int nk = (a.Ktot + BK - 1) / BK;
+  const int nk = kt1 > kt0 ? kt1 - kt0 : 0;
 
   __syncthreads();   // taps visible
 
@@ -206,73 +289,150 @@ __global__ __launch_bounds__(256, 2) void conv_gather_kernel(const GatherArgs a)
     __syncthreads();
   }
 
-  // ---- epilogue: bias + activation in registers, transpose through LDS, 16-B stores ----------
-  const float* bias = a.bias ? a.bias + (size_t)g * a.Cout : nullptr;
+  conv_epilogue<T, BCO, BPIX, TCO, TPIX>(a, acc, smem, rowoff, g, co_base, wco0, wpix0, r, h, tid);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fast path (bf16, Cin % 64 == 0, zero padding, tensors < 2 GiB): the bulk of the FLOPs.
+//   * BK = 64: one K step = one tap x 64 channels, so the tap is block-uniform (scalar) and steps are twice as long
+//     (16 MFMAs per wave between barriers);
+//   * global loads are buffer loads with a hardware range check: an invalid gather (padding, row >= M, co >= Cout)
+//     is expressed as an out-of-range offset that returns zeros -- no exec-mask branches, no per-load predicates;
+//   * validity of (pixel row, tap) is a 64-bit mask computed once per row; per step it costs a shift and a select;
+//   * all offsets are 32-bit byte offsets (host checks the tensors are < 2 GiB).
+template <int BCO, int BPIX, int WCO, int WPIX>
+__global__ __launch_bounds__(256, 2) void conv_fast_kernel(const GatherArgs a) {
+  typedef __bf16 T;
+  constexpr int CE = 8, BK = 64, RS = 144;           // 128 B of K per row + 16 B pad (conflict-free ds_read_b128)
+  constexpr int TCO = BCO / WCO / 32, TPIX = BPIX / WPIX / 32;
+  constexpr int NLW = BCO / 32, NLP = BPIX / 32;
+  constexpr int STAGE = (BCO + BPIX) * RS;
+  constexpr int ERS = BCO * 2 + 16;
+  constexpr int EPI = BPIX * ERS;
+  constexpr int MAIN = (2 * STAGE > EPI ? 2 * STAGE : EPI);
+  __shared__ __attribute__((aligned(16))) char smem[MAIN + BPIX * 4];
+  int* rowoff = (int*)(smem + MAIN);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int g = blockIdx.y;
+  int nblk = a.npix_tiles * a.nco_tiles;
+  int bid = blockIdx.x;
+  {
+    int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, k = bid >> 3;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+  }
+  const int co_tile = bid % a.nco_tiles, pix_tile = bid / a.nco_tiles;
+  const int co_base = co_tile * BCO, pix_base = pix_tile * BPIX;
+  const int QQ = a.Qh * a.Qw;
+  if (tid < BPIX) {
+    int m = pix_base + tid;
+    int off = -1;
+    if (m < a.M) {
+      int n = m / QQ, rr = m - n * QQ, qy = rr / a.Qw, qx = rr - qy * a.Qw;
+      off = ((n * a.Ho + qy * a.ostride + a.oy0) * a.Wo + qx * a.ostride + a.ox0);
+    }
+    rowoff[tid] = off;
+  }
+
+  const int jc = tid & 7, r0 = tid >> 3;            // 16-B chunk column (8 per row), row 0..31 (+32*i)
+  const unsigned OOB = 0x80000000u;
+  const T* xg = (const T*)a.x + (size_t)g * a.x_gstride;
+  const T* wg = (const T*)a.w + (size_t)g * a.w_gstride;
+  __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, a.x_bytes - (unsigned)g * (unsigned)a.x_gstride * 2u, 0x00020000);
+  __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, a.w_bytes, 0x00020000);
+
+  unsigned p_byte[NLP];
+  unsigned long long p_mask[NLP];
 #pragma unroll
-  for (int i = 0; i < TCO; ++i) {
-#pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) {
-      int col = wco0 + 32 * i + 8 * q4 + 4 * h;     // local co of element e=0
-      float bv[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        int co = co_base + col + e;
-        bv[e] = (bias && co < a.Cout) ? bias[co] : 0.f;
-      }
-#pragma unroll
-      for (int j = 0; j < TPIX; ++j) {
-        int prow_l = wpix0 + 32 * j + r;
-        char* dst = smem + prow_l * ERS + col * (int)sizeof(T);
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = act_fwd(acc[i][j][4 * q4 + e] + bv[e], a.act, a.slope);
-        if constexpr (sizeof(T) == 2) {
-          bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-          *(bf16x4*)dst = o;
-        } else {
-          f32x4 o = {v[0], v[1], v[2], v[3]};
-          *(f32x4*)dst = o;
-        }
+  for (int i = 0; i < NLP; ++i) {
+    int m = pix_base + r0 + 32 * i;
+    unsigned long long mask = 0ull;
+    unsigned byte = 0u;
+    if (m < a.M) {
+      int n = m / QQ, rr = m - n * QQ, qy = rr / a.Qw, qx = rr - qy * a.Qw;
+      int py = qy * a.istride, px = qx * a.istride;
+      byte = (unsigned)(((n * a.Hi + py) * a.Wi + px) * a.x_pitch * 2 + jc * 16);
+      for (int t = 0; t < a.T; ++t) {
+        int ti = a.tap[t];
+        int iy = py + (int)(signed char)(ti & 0xff), ix = px + (int)(signed char)((ti >> 8) & 0xff);
+        if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) mask |= 1ull << t;
       }
     }
+    p_byte[i] = byte; p_mask[i] = mask;
   }
+  unsigned w_byte[NLW];
+#pragma unroll
+  for (int i = 0; i < NLW; ++i) {
+    int co = co_base + r0 + 32 * i;
+    w_byte[i] = co < a.Cout ? (unsigned)(co * a.w_row * 2 + jc * 16) : OOB;
+  }
+
+  u32x4 regW[NLW], regP[NLP];
+  const int nk = a.Ktot / BK;
+  int tap = 0, c0 = 0;                                // block-uniform K position
+
+  auto load_global = [&]() {
+    const int ti = a.tap[tap];
+    const int dy = (int)(signed char)(ti & 0xff), dx = (int)(signed char)((ti >> 8) & 0xff), wt = ti >> 16;
+    const int toff = ((dy * a.Wi + dx) * a.x_pitch + c0) * 2;
+    const int woff = (wt * a.Cin + c0) * 2;
+#pragma unroll
+    for (int i = 0; i < NLW; ++i)
+      regW[i] = __builtin_amdgcn_raw_buffer_load_b128(wr, (int)(w_byte[i] == OOB ? OOB : w_byte[i] + (unsigned)woff), 0, 0);
+#pragma unroll
+    for (int i = 0; i < NLP; ++i) {
+      bool ok = (p_mask[i] >> tap) & 1ull;
+      regP[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(ok ? p_byte[i] + (unsigned)toff : OOB), 0, 0);
+    }
+    c0 += BK;
+    if (c0 >= a.Cin) { c0 = 0; ++tap; }
+  };
+  auto store_lds = [&](int buf) {
+    char* base = smem + buf * STAGE + r0 * RS + jc * 16;
+#pragma unroll
+    for (int i = 0; i < NLW; ++i) *(u32x4*)(base + 32 * i * RS) = regW[i];
+#pragma unroll
+    for (int i = 0; i < NLP; ++i) *(u32x4*)(base + (BCO + 32 * i) * RS) = regP[i];
+  };
+
+  f32x16 acc[TCO][TPIX];
+#pragma unroll
+  for (int i = 0; i < TCO; ++i)
+#pragma unroll
+    for (int j = 0; j < TPIX; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int wco0 = (wave / WPIX) * (TCO * 32);
+  const int wpix0 = (wave % WPIX) * (TPIX * 32);
+
+  if (nk > 0) { load_global(); store_lds(0); }
   __syncthreads();
-  constexpr int CPR = BCO / CE;
-  T* yg = (T*)a.y + (size_t)g * a.y_gstride;
-  const T* auxg = a.aux ? (const T*)a.aux + (size_t)g * a.y_gstride : nullptr;
-  const T* aux2g = a.aux2 ? (const T*)a.aux2 + (size_t)g * a.y_gstride : nullptr;
-  for (int idx = tid; idx < BPIX * CPR; idx += 256) {
-    int row = idx / CPR, ch = idx - row * CPR;
-    int off = rowoff[row];
-    int co0 = co_base + ch * CE;
-    if (off < 0 || co0 >= a.Cst) continue;
-    Chunk<T> c;
-    c.raw = *(const u32x4*)(smem + row * ERS + ch * 16);
-    size_t go = (size_t)off * a.y_pitch + co0;
-    bool full = co0 + CE <= a.Cst;
-    if (a.epi != S2P_EPI_STORE) {
-      Chunk<T> x, x2;
-      x2.raw = (u32x4){0u, 0u, 0u, 0u};
-      if (full) {
-        x.raw = *(const u32x4*)(auxg + go);
-        if (aux2g) x2.raw = *(const u32x4*)(aux2g + go);
-      } else {
-        x.raw = (u32x4){0u, 0u, 0u, 0u};
-        for (int e = 0; e < CE; ++e) if (co0 + e < a.Cst) {
-          x.set(e, to_f32(auxg[go + e]));
-          if (aux2g) x2.set(e, to_f32(aux2g[go + e]));
-        }
-      }
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) load_global();
+    const char* base = smem + (kt & 1) * STAGE;
+    const char* wrow = base + (wco0 + r) * RS + h * 16;
+    const char* prow = base + (BCO + wpix0 + r) * RS + h * 16;
 #pragma unroll
-      for (int e = 0; e < CE; ++e) {
-        float v = c.get(e), xv = x.get(e);
-        v = (a.epi == S2P_EPI_ADD) ? v + xv : (v + x2.get(e)) * act_grad_from_out(xv, a.gact, a.gslope);
-        c.set(e, v);
-      }
+    for (int s = 0; s < 4; ++s) {
+      bf16x8 af[TCO], bf[TPIX];
+#pragma unroll
+      for (int i = 0; i < TCO; ++i) af[i] = *(const bf16x8*)(wrow + i * 32 * RS + s * 32);
+#pragma unroll
+      for (int j = 0; j < TPIX; ++j) bf[j] = *(const bf16x8*)(prow + j * 32 * RS + s * 32);
+#pragma unroll
+      for (int i = 0; i < TCO; ++i)
+#pragma unroll
+        for (int j = 0; j < TPIX; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
-    if (full) *(u32x4*)(yg + go) = c.raw;
-    else for (int e = 0; e < CE; ++e) if (co0 + e < a.Cst) yg[go + e] = from_f32<T>(c.get(e));
+    if (more) store_lds((kt + 1) & 1);
+    __syncthreads();
   }
+  conv_epilogue<T, BCO, BPIX, TCO, TPIX>(a, acc, smem, rowoff, g, co_base, wco0, wpix0, r, h, tid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -280,15 +440,196 @@ template <typename T, int BCO, int BPIX, int WCO, int WPIX>
 static int launch_cfg(GatherArgs& a, int groups, hipStream_t st) {
   a.npix_tiles = cdiv(a.M, BPIX);
   a.nco_tiles = cdiv(a.Cst, BCO);
-  dim3 grid(a.npix_tiles * a.nco_tiles, groups);
+  int splits = 1;
+  a.splitk = 1; a.ksteps = 0;
+  if (sizeof(T) == 4 && a.act == S2P_ACT_NONE && a.epi == S2P_EPI_STORE) {
+    // latency-bound fp32 linear layers (tiny M, long K, a handful of tiles): split K, accumulate with fp32 atomics
+    const int nk = cdiv(a.Ktot, Mma<T>::BK);
+    const int tiles = a.npix_tiles * a.nco_tiles * groups;
+    if (tiles < 64 && nk >= 32) {
+      splits = 256 / tiles; if (splits > nk / 8) splits = nk / 8; if (splits < 1) splits = 1;
+      if (splits > 1) {
+        a.ksteps = cdiv(nk, splits); splits = cdiv(nk, a.ksteps); a.splitk = splits;
+        // y must start from zero: clear exactly the region this launch owns (rows of Cst channels)
+        if (a.ostride != 1 || groups != 1 || a.Cst != a.y_pitch) { a.splitk = 1; splits = 1; }
+        else if (hipMemsetAsync(a.y, 0, (size_t)a.M * a.y_pitch * sizeof(T), st) != hipSuccess) { a.splitk = 1; splits = 1; }
+      }
+    }
+  }
+  dim3 grid(a.npix_tiles * a.nco_tiles, groups, splits);
   hipLaunchKernelGGL((conv_gather_kernel<T, BCO, BPIX, WCO, WPIX>), grid, dim3(256), 0, st, a);
   S2P_CHECK_LAUNCH("conv_gather_kernel");
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant of the fast path: `buffer_load_dwordx4 ... lds` writes the staged tile straight into LDS, so the
+// register->LDS `ds_write_b128` pass (13 cycles per wave-instruction; with two co-resident workgroups it made the
+// kernel LDS-bound) disappears, and so do the 32 staging VGPRs.  An LDS-DMA wave-instruction writes 1 KiB linearly
+// (8 rows of 128 B), so rows cannot be padded; bank conflicts are avoided with an XOR swizzle of the 16-byte chunk
+// index, chunk' = chunk ^ ((row >> 1) & 7), applied on the per-lane global SOURCE address and again on the
+// fragment read (conflict-free for the 16-lane groups of ds_read_b128 with 128-byte rows).
+template <int BCO, int BPIX, int WCO, int WPIX>
+__global__ __launch_bounds__(256, 2) void conv_dma_kernel(const GatherArgs a) {
+  typedef __bf16 T;
+  constexpr int BK = 64, RS = 128;
+  constexpr int TCO = BCO / WCO / 32, TPIX = BPIX / WPIX / 32;
+  constexpr int NI = (BCO + BPIX) / 32;              // DMA instructions per wave per K step (8 rows each, 4 waves)
+  constexpr int NIW = BCO / 32;                      // the first NIW of them stage weight rows
+  constexpr int STAGE = (BCO + BPIX) * RS;
+  constexpr int ERS = BCO * 2 + 16;
+  constexpr int EPI = BPIX * ERS;
+  constexpr int MAIN = (2 * STAGE > EPI ? 2 * STAGE : EPI);
+  __shared__ __attribute__((aligned(1024))) char smem[MAIN + BPIX * 4];
+  int* rowoff = (int*)(smem + MAIN);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int g = blockIdx.y;
+  int nblk = a.npix_tiles * a.nco_tiles;
+  int bid = blockIdx.x;
+  {
+    int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, k = bid >> 3;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+  }
+  const int co_tile = bid % a.nco_tiles, pix_tile = bid / a.nco_tiles;
+  const int co_base = co_tile * BCO, pix_base = pix_tile * BPIX;
+  const int QQ = a.Qh * a.Qw;
+  if (tid < BPIX) {
+    int m = pix_base + tid;
+    int off = -1;
+    if (m < a.M) {
+      int n = m / QQ, rr = m - n * QQ, qy = rr / a.Qw, qx = rr - qy * a.Qw;
+      off = ((n * a.Ho + qy * a.ostride + a.oy0) * a.Wo + qx * a.ostride + a.ox0);
+    }
+    rowoff[tid] = off;
+  }
+
+  const unsigned OOB = 0x80000000u;
+  const T* xg = (const T*)a.x + (size_t)g * a.x_gstride;
+  const T* wg = (const T*)a.w + (size_t)g * a.w_gstride;
+  __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, a.x_bytes - (unsigned)g * (unsigned)a.x_gstride * 2u, 0x00020000);
+  __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, a.w_bytes, 0x00020000);
+
+  // lane -> (row inside the 8-row piece, physical chunk); instruction i of wave w stages rows (4i + w)*8 .. +7
+  const int lrow = lane >> 3, pc = lane & 7;
+  unsigned w_byte[NIW];
+  unsigned p_byte[NI - NIW];
+  unsigned long long p_mask[NI - NIW];
+#pragma unroll
+  for (int i = 0; i < NIW; ++i) {
+    int row = (4 * i + wave) * 8 + lrow;
+    int c = pc ^ ((row >> 1) & 7);
+    int co = co_base + row;
+    w_byte[i] = co < a.Cout ? (unsigned)(co * a.w_row * 2 + c * 16) : OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < NI - NIW; ++i) {
+    int row = (4 * (i + NIW) + wave) * 8 + lrow;      // stage row (>= BCO)
+    int c = pc ^ ((row >> 1) & 7);
+    int m = pix_base + row - BCO;
+    unsigned long long mask = 0ull;
+    unsigned byte = 0u;
+    if (m < a.M) {
+      int n = m / QQ, rr = m - n * QQ, qy = rr / a.Qw, qx = rr - qy * a.Qw;
+      int py = qy * a.istride, px = qx * a.istride;
+      byte = (unsigned)(((n * a.Hi + py) * a.Wi + px) * a.x_pitch * 2 + c * 16);
+      for (int t = 0; t < a.T; ++t) {
+        int ti = a.tap[t];
+        int iy = py + (int)(signed char)(ti & 0xff), ix = px + (int)(signed char)((ti >> 8) & 0xff);
+        if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) mask |= 1ull << t;
+      }
+    }
+    p_byte[i] = byte; p_mask[i] = mask;
+  }
+
+  const int nk = a.Ktot / BK;
+  int tap = 0, c0 = 0;                                // block-uniform K position
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+
+  auto issue = [&](int buf) {
+    const int ti = a.tap[tap];
+    const int dy = (int)(signed char)(ti & 0xff), dx = (int)(signed char)((ti >> 8) & 0xff), wt = ti >> 16;
+    const int toff = ((dy * a.Wi + dx) * a.x_pitch + c0) * 2;
+    const int woff = (wt * a.Cin + c0) * 2;
+    char* base = smem + buf * STAGE + wave * (8 * RS);
+#pragma unroll
+    for (int i = 0; i < NIW; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(base + i * (32 * RS)), 16,
+                                               (int)(w_byte[i] == OOB ? OOB : w_byte[i] + (unsigned)woff), 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NI - NIW; ++i) {
+      bool ok = (p_mask[i] >> tap) & 1ull;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(base + (i + NIW) * (32 * RS)), 16,
+                                               (int)(ok ? p_byte[i] + (unsigned)toff : OOB), 0, 0, 0);
+    }
+    c0 += BK;
+    if (c0 >= a.Cin) { c0 = 0; ++tap; }
+  };
+
+  f32x16 acc[TCO][TPIX];
+#pragma unroll
+  for (int i = 0; i < TCO; ++i)
+#pragma unroll
+    for (int j = 0; j < TPIX; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int wco0 = (wave / WPIX) * (TCO * 32);
+  const int wpix0 = (wave % WPIX) * (TPIX * 32);
+  const int sw = (r >> 1) & 7;                        // read-side swizzle (tile bases are multiples of 16 rows)
+
+  if (nk > 0) issue(0);
+  __syncthreads();                                    // hipcc drains vmcnt before the barrier (LDS-DMA in flight)
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) issue((kt + 1) & 1);
+    const char* base = smem + (kt & 1) * STAGE;
+    const char* wrow = base + (wco0 + r) * RS;
+    const char* prow = base + (BCO + wpix0 + r) * RS;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int ch = ((2 * s + h) ^ sw) * 16;
+      bf16x8 af[TCO], bf[TPIX];
+#pragma unroll
+      for (int i = 0; i < TCO; ++i) af[i] = *(const bf16x8*)(wrow + i * 32 * RS + ch);
+#pragma unroll
+      for (int j = 0; j < TPIX; ++j) bf[j] = *(const bf16x8*)(prow + j * 32 * RS + ch);
+#pragma unroll
+      for (int i = 0; i < TCO; ++i)
+#pragma unroll
+        for (int j = 0; j < TPIX; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  conv_epilogue<T, BCO, BPIX, TCO, TPIX>(a, acc, smem, rowoff, g, co_base, wco0, wpix0, r, h, tid);
+}
+
+template <int BCO, int BPIX, int WCO, int WPIX>
+static int launch_fast(GatherArgs& a, int groups, hipStream_t st) {
+  a.npix_tiles = cdiv(a.M, BPIX);
+  a.nco_tiles = cdiv(a.Cst, BCO);
+  dim3 grid(a.npix_tiles * a.nco_tiles, groups);
+  static const int no_dma = getenv("S2P_NO_LDS_DMA") ? 1 : 0;      // A/B switch: register-staged fast kernel
+  if (no_dma) hipLaunchKernelGGL((conv_fast_kernel<BCO, BPIX, WCO, WPIX>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv_dma_kernel<BCO, BPIX, WCO, WPIX>), grid, dim3(256), 0, st, a);
+  S2P_CHECK_LAUNCH("conv_fast_kernel");
+  return 0;
+}
+
 template <typename T>
-static int launch_gather(GatherArgs& a, int groups, hipStream_t st) {
+static int launch_gather(GatherArgs& a, int groups, long long x_elems, hipStream_t st) {
   if (a.M <= 0) return 0;
+  if constexpr (sizeof(T) == 2) {
+    const long long xb = x_elems * 2, wb = (long long)a.Cout * a.w_row * 2;
+    if (a.Cin % 64 == 0 && !a.reflect && a.T > 0 && xb < (1ll << 31) && wb < (1ll << 31) && a.Cst > 32) {
+      a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
+      if (a.Cst > 64) return launch_fast<128, 128, 2, 2>(a, groups, st);
+      return launch_fast<64, 128, 2, 2>(a, groups, st);
+    }
+  }
   if (a.Cst > 64) return launch_cfg<T, 128, 128, 2, 2>(a, groups, st);
   if (a.Cst > 32) return launch_cfg<T, 64, 128, 2, 2>(a, groups, st);
   return launch_cfg<T, 32, 256, 1, 4>(a, groups, st);
@@ -318,7 +659,7 @@ static int run_gather(const Geo& G, const void* x, const void* w, const float* b
   if (a.T > MAX_TAPS) S2P_FAIL(-2, "conv: more than %d taps", MAX_TAPS);
   for (int ky = 0; ky < G.KH; ++ky)
     for (int kx = 0; kx < G.KW; ++kx) a.tap[ky * G.KW + kx] = pack_tap(ky - G.pad, kx - G.pad, ky * G.KW + kx);
-  return launch_gather<T>(a, G.groups, st);
+  return launch_gather<T>(a, G.groups, (long long)G.N * G.Hi * G.Wi * G.xp, st);
 }
 
 // "scatter" orientation expressed per output phase: out(oy) = sum_k in((oy + pad - k)/stride)
@@ -351,7 +692,7 @@ static int run_scatter(const Geo& G, const void* x, const void* w, const float* 
         }
       }
       a.T = t; a.Ktot = t * G.Ci;
-      int rc = launch_gather<T>(a, G.groups, st);
+      int rc = launch_gather<T>(a, G.groups, (long long)G.N * G.Hi * G.Wi * G.xp, st);
       if (rc) return rc;
     }
   return 0;
@@ -379,6 +720,7 @@ extern "C" int s2p_conv2d_fwd(const s2p_conv_desc* d, const void* x, const void*
   if (epi != S2P_EPI_STORE && !aux) S2P_FAIL(-1, "s2p_conv2d_fwd: epi needs aux");
   hipStream_t st = (hipStream_t)stream;
   int ce = d->dtype == S2P_F32 ? 4 : 8;
+  if (epi == S2P_EPI_STORE && s2p_thin_applicable(d)) return s2p_thin_fwd(d, x, w_fwd, bias, y, act, slope, st);
   Geo G{d->N, d->H, d->W, d->Cin, d->x_pitch, d->x_gstride, d->Ho, d->Wo, d->Cout,
         /*Cst*/ d->groups == 1 ? ((d->Cout + ce - 1) / ce * ce <= d->y_pitch ? (d->Cout + ce - 1) / ce * ce : d->Cout)
                                : d->Cout,

@@ -103,52 +103,63 @@ __global__ __launch_bounds__(256) void in_reduce_kernel(const NormArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // elementwise passes.  MODE 0: forward apply.  MODE 1: backward apply (dx, dgamma_img, dbeta_img).
+// Same thread geometry as the reductions: a thread owns one 16-byte channel chunk of one image and walks a pixel
+// stripe, so every per-(n,c) constant (mean, rstd, state gamma/beta, backward sums) is computed ONCE per thread and
+// the loop body is pure streaming: 16-B loads, a few FMAs per element, 16-B stores.
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void in_apply_kernel(const NormArgs a) {
   constexpr int CE = DT<T>::CE;
-  const int cpr = a.C / CE;                                  // chunks per pixel
-  const long long total = (long long)a.N * a.HW * cpr;
+  constexpr int CS = 64, NCH = CS / CE, PR = 256 / NCH;
+  const int tid = threadIdx.x, cc = tid % NCH, pr = tid / NCH;
+  const int n = blockIdx.y, c0 = blockIdx.x * CS + cc * CE;
+  if (c0 >= a.C) return;
+  const int p_begin = blockIdx.z * a.rows_per_split;
+  int p_end = p_begin + a.rows_per_split;
+  if (p_end > a.HW) p_end = a.HW;
   const float invHW = 1.f / (float)a.HW;
-  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-    long long pix = idx / cpr;
-    int c0 = (int)(idx - pix * cpr) * CE;
-    int n = (int)(pix / a.HW);
-    Chunk<T> xv; xv.raw = *(const u32x4*)((const T*)a.x + (size_t)pix * a.x_pitch + c0);
-    Chunk<T> gv, bv;
-    if (a.gb) {
-      const T* gp = (const T*)a.gb + (size_t)pix * a.gb_pitch + c0;
-      gv.raw = *(const u32x4*)gp; bv.raw = *(const u32x4*)(gp + a.C);
+  float mean[CE], rstd[CE], gs[CE], bs[CE], s1[CE], s2[CE];
+#pragma unroll
+  for (int e = 0; e < CE; ++e) {
+    mean_rstd(a.stats, n, a.C, c0 + e, a.HW, a.eps, mean[e], rstd[e]);
+    gs[e] = 1.f + (a.gbst ? a.gbst[(size_t)n * a.gbst_pitch + c0 + e] : 0.f);
+    bs[e] = a.gbst ? a.gbst[(size_t)n * a.gbst_pitch + a.C + c0 + e] : 0.f;
+    if (MODE == 1) {
+      const float* sm = a.sums + ((size_t)n * a.C + c0 + e) * 4;
+      s1[e] = sm[0] * invHW; s2[e] = sm[1] * invHW;
     }
-    Chunk<T> dv;
-    if (MODE == 1) dv.raw = *(const u32x4*)((const T*)a.da + (size_t)pix * a.da_pitch + c0);
+  }
+  const size_t img = (size_t)n * a.HW;
+  const T* xb = (const T*)a.x + img * a.x_pitch + c0;
+  const T* gbb = a.gb ? (const T*)a.gb + img * a.gb_pitch + c0 : nullptr;
+  const T* dab = MODE == 1 ? (const T*)a.da + img * a.da_pitch + c0 : nullptr;
+  T* yb = (T*)a.y + img * a.y_pitch + c0;
+  T* dgb = (MODE == 1 && a.dgb) ? (T*)a.dgb + img * a.dgb_pitch + c0 : nullptr;
+  for (int p = p_begin + pr; p < p_end; p += PR) {
+    Chunk<T> xv; xv.raw = *(const u32x4*)(xb + (size_t)p * a.x_pitch);
+    Chunk<T> gv, bv, dv;
+    if (gbb) { gv.raw = *(const u32x4*)(gbb + (size_t)p * a.gb_pitch); bv.raw = *(const u32x4*)(gbb + (size_t)p * a.gb_pitch + a.C); }
+    if (MODE == 1) dv.raw = *(const u32x4*)(dab + (size_t)p * a.da_pitch);
     Chunk<T> o0, o1, o2;
 #pragma unroll
     for (int e = 0; e < CE; ++e) {
-      float mean, rstd;
-      mean_rstd(a.stats, n, a.C, c0 + e, a.HW, a.eps, mean, rstd);
-      float gg = 1.f + (a.gbst ? a.gbst[(size_t)n * a.gbst_pitch + c0 + e] : 0.f) + (a.gb ? gv.get(e) : 0.f);
-      float bb = (a.gbst ? a.gbst[(size_t)n * a.gbst_pitch + a.C + c0 + e] : 0.f) + (a.gb ? bv.get(e) : 0.f);
-      float xh = (xv.get(e) - mean) * rstd;
+      float gg = gs[e] + (gbb ? gv.get(e) : 0.f);
+      float bb = bs[e] + (gbb ? bv.get(e) : 0.f);
+      float xh = (xv.get(e) - mean[e]) * rstd[e];
       float yv = xh * gg + bb;
       if (MODE == 0) {
         o0.set(e, act_fwd(yv, a.act, a.slope));
       } else {
         float dy = dv.get(e) * act_grad_from_out(yv, a.act, a.slope);
         float dxh = dy * gg;
-        const float* sm = a.sums + ((size_t)n * a.C + c0 + e) * 4;
-        o0.set(e, rstd * (dxh - sm[0] * invHW - xh * sm[1] * invHW));
+        o0.set(e, rstd[e] * (dxh - s1[e] - xh * s2[e]));
         o1.set(e, dy * xh);
         o2.set(e, dy);
       }
     }
-    if (MODE == 0) {
-      *(u32x4*)((T*)a.y + (size_t)pix * a.y_pitch + c0) = o0.raw;
-    } else {
-      *(u32x4*)((T*)a.y + (size_t)pix * a.y_pitch + c0) = o0.raw;
-      if (a.dgb) {
-        T* dp = (T*)a.dgb + (size_t)pix * a.dgb_pitch + c0;
-        *(u32x4*)dp = o1.raw; *(u32x4*)(dp + a.C) = o2.raw;
-      }
+    *(u32x4*)(yb + (size_t)p * a.y_pitch) = o0.raw;
+    if (MODE == 1 && dgb) {
+      *(u32x4*)(dgb + (size_t)p * a.dgb_pitch) = o1.raw;
+      *(u32x4*)(dgb + (size_t)p * a.dgb_pitch + a.C) = o2.raw;
     }
   }
 }
@@ -198,21 +209,26 @@ static int norm_check(const char* who, int dtype, int C, int p0, int p1, int p2)
 
 template <int MODE>
 static int launch_reduce(int dtype, NormArgs& a, hipStream_t st) {
-  int ps = a.HW / 512; if (ps < 1) ps = 1; if (ps > 16) ps = 16;
+  int slabs = cdiv(a.C, 64);
+  int ps = cdiv(1024, slabs * a.N);                     // aim at >= 1024 workgroups
+  int maxps = cdiv(a.HW, 128); if (ps > maxps) ps = maxps; if (ps < 1) ps = 1;
   a.psplit = ps; a.rows_per_split = cdiv(a.HW, ps);
-  dim3 grid(cdiv(a.C, 64), a.N, ps);
+  dim3 grid(slabs, a.N, cdiv(a.HW, a.rows_per_split));
   if (dtype == S2P_F32) hipLaunchKernelGGL((in_reduce_kernel<float, MODE>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((in_reduce_kernel<__bf16, MODE>), grid, dim3(256), 0, st, a);
   S2P_CHECK_LAUNCH("in_reduce_kernel");
   return 0;
 }
+
 template <int MODE>
 static int launch_apply(int dtype, NormArgs& a, hipStream_t st) {
-  int ce = dtype == S2P_F32 ? 4 : 8;
-  long long total = (long long)a.N * a.HW * (a.C / ce);
-  int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
-  if (dtype == S2P_F32) hipLaunchKernelGGL((in_apply_kernel<float, MODE>), dim3(blocks), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((in_apply_kernel<__bf16, MODE>), dim3(blocks), dim3(256), 0, st, a);
+  int slabs = cdiv(a.C, 64);
+  int ps = cdiv(2048, slabs * a.N);                     // aim at >= 2048 workgroups (8 per CU)
+  int maxps = cdiv(a.HW, 64); if (ps > maxps) ps = maxps; if (ps < 1) ps = 1;
+  a.psplit = ps; a.rows_per_split = cdiv(a.HW, ps);
+  dim3 grid(slabs, a.N, cdiv(a.HW, a.rows_per_split));
+  if (dtype == S2P_F32) hipLaunchKernelGGL((in_apply_kernel<float, MODE>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((in_apply_kernel<__bf16, MODE>), grid, dim3(256), 0, st, a);
   S2P_CHECK_LAUNCH("in_apply_kernel");
   return 0;
 }

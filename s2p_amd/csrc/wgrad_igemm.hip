@@ -200,6 +200,7 @@ extern "C" int s2p_conv2d_wgrad(const s2p_conv_desc* d, const void* x, const voi
   if (T > 64) S2P_FAIL(-2, "s2p_conv2d_wgrad: more than 64 taps");
   const int cout_pad = (d->Cout + ce - 1) / ce * ce;
   if (cout_pad > d->y_pitch) S2P_FAIL(-1, "s2p_conv2d_wgrad: dy pitch < padded Cout");
+  if (s2p_thin_applicable(d) && cout_real == d->Cout) return s2p_thin_wgrad(d, x, dy, dw, cin_real, (hipStream_t)stream);
   WgradArgs a{};
   a.dW = dw;
   a.istride = d->stride; a.reflect = d->reflect; a.T = T;
