@@ -76,8 +76,10 @@ int s2p_conv2d_dgrad(const s2p_conv_desc* d, const void* dy, const void* w_bwd,
 /* dw (fp32) [groups][Cout][KH*KW][Cin_real] for transposed==0,
  *           [groups][Cin][KH*KW][Cout_real] for transposed==1  (= channels-last physical
  * layout of the torch parameter).  dw is ACCUMULATED into (caller zeroes it);
- * dw_gstride = elements between groups.  cin_real/cout_real: un-padded channel counts.  */
-int s2p_conv2d_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw,
+ * dw_gstride = elements between groups.  cin_real/cout_real: un-padded channel counts.
+ * db (may be NULL; transposed==0 only): fp32 [groups][Cout] bias gradient, ACCUMULATED into,
+ * fused into the same pass over dy.                                                     */
+int s2p_conv2d_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, float* db,
                      int cin_real, int cout_real, int64_t dw_gstride, int splitk, void* stream);
 /* adjoint of F.pad(mode='reflect'): dx[N,H,W,C] = fold(dxp[N,H+2p,W+2p,C])              */
 int s2p_reflect_pad_bwd(int dtype, const void* dxp, int N, int H, int W, int C, int pad, void* dx,

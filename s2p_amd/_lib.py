@@ -40,7 +40,7 @@ SIGNATURES = {
     "s2p_last_error": [],
     "s2p_conv2d_fwd": [_DESC, _P, _P, _P, _P, _P, c_int, c_float, c_int, _P],
     "s2p_conv2d_dgrad": [_DESC, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P],
-    "s2p_conv2d_wgrad": [_DESC, _P, _P, _P, c_int, c_int, c_int64, c_int, _P],
+    "s2p_conv2d_wgrad": [_DESC, _P, _P, _P, _P, c_int, c_int, c_int64, c_int, _P],
     "s2p_reflect_pad_bwd": [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P],
     "s2p_channel_sum": [c_int, _P, c_int64, c_int, c_int, _P, _P],
     "s2p_in_stats": [c_int, _P, c_int, c_int, c_int, c_int, c_float, _P, _P],

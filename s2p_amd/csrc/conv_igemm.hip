@@ -28,6 +28,7 @@ struct GatherArgs {
   int reflect, act, epi, gact;
   float slope, gslope;
   int npix_tiles, nco_tiles;
+  int diag;                    // timing-only ablation (S2P_DIAG env): 1 = skip in-loop loads, 2 = skip MFMAs
   int splitk, ksteps;          // generic fp32 path only: split-K over blockIdx.z with fp32 atomics into a zeroed y
   unsigned x_bytes, w_bytes;   // fast path: buffer-descriptor sizes of the gathered tensor / packed weights (per group view)
   int tap[MAX_TAPS];   // (wt << 16) | ((dx & 0xff) << 8) | (dy & 0xff)
@@ -584,10 +585,11 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const GatherArgs a) {
   if (nk > 0) issue(0);
   __syncthreads();                                    // hipcc drains vmcnt before the barrier (LDS-DMA in flight)
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) issue((kt + 1) & 1);
+    if (kt + 1 < nk && a.diag != 1) issue((kt + 1) & 1);
     const char* base = smem + (kt & 1) * STAGE;
     const char* wrow = base + (wco0 + r) * RS;
     const char* prow = base + (BCO + wpix0 + r) * RS;
+    if (a.diag != 2)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int ch = ((2 * s + h) ^ sw) * 16;
@@ -612,7 +614,9 @@ static int launch_fast(GatherArgs& a, int groups, hipStream_t st) {
   a.npix_tiles = cdiv(a.M, BPIX);
   a.nco_tiles = cdiv(a.Cst, BCO);
   dim3 grid(a.npix_tiles * a.nco_tiles, groups);
-  static const int no_dma = getenv("S2P_NO_LDS_DMA") ? 1 : 0;      // A/B switch: register-staged fast kernel
+  static const int no_dma = getenv("S2P_NO_LDS_DMA") ? 1 : 0;
+  static const int diag = getenv("S2P_DIAG") ? atoi(getenv("S2P_DIAG")) : 0;
+  a.diag = diag;      // A/B switch: register-staged fast kernel
   if (no_dma) hipLaunchKernelGGL((conv_fast_kernel<BCO, BPIX, WCO, WPIX>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((conv_dma_kernel<BCO, BPIX, WCO, WPIX>), grid, dim3(256), 0, st, a);
   S2P_CHECK_LAUNCH("conv_fast_kernel");

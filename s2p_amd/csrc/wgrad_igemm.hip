@@ -8,9 +8,13 @@
 // so that the four k-rows of one transposed read fall on disjoint banks.  Split-K over the pixel axis with
 // fp32 atomics whose wave-instruction shape is two 128-B row segments (the full-rate shape on this chip).
 #include "s2p_common.h"
+#include <stdlib.h>
 
 struct WgradArgs {
-  const void* A; const void* B; float* dW;
+  const void* A; const void* B; float* dW; float* db;
+  unsigned a_bytes, b_bytes;
+  int diag;
+  int groups, xcd_map;          // DMA kernel: 1-D grid, all tiles of one (group, split) unit on one XCD
   int M, Qh, Qw;                // pixel grid of A
   int Ca, a_pitch, a_gstride;   // A channels (multiple of CE), pitch
   int Ca_real;                  // rows of dW actually written
@@ -189,7 +193,193 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   }
 }
 
-extern "C" int s2p_conv2d_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw,
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant (bf16, tensors < 2 GiB): both operand tiles go HBM -> LDS with `buffer_load_dwordx4 ... lds`
+// (no register staging, no ds_write pass, out-of-range rows / columns / padding taps come back as zeros from the
+// buffer range check).  Rows are 256 B unpadded; the 16-byte chunk index is XOR-swizzled with
+// ((row & 3) << 2) | ((row >> 2) & 3) on the source address and on the transposed read, which keeps
+// ds_read_b64_tr_b16 conflict-free (one image serves the 32x32x16 A and B fragments).
+// Workgroups of B-tile 0 also accumulate the bias gradient  db[a] += sum_m A[m][a]  with one extra MFMA against a
+// ones fragment per A fragment, so dY is not read a second time by a separate reduction kernel.
+template <int BKP>
+__global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
+  typedef __bf16 T;
+  constexpr int BT = 128, RS = 256, TT = 2;
+  constexpr int NP = BKP / 16;                        // DMA pieces (4 rows) per wave per operand per step
+  constexpr int TILE = BKP * RS;                      // 8 KiB per operand
+  __shared__ __attribute__((aligned(1024))) char smem[4 * TILE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // XCD-aware mapping: workgroups b, b+8, ... share an XCD (and its 4 MiB L2).  All tiles of one (group, split)
+  // unit read the SAME pixel rows, so a unit is kept on one XCD: its rows stream into that L2 once and serve
+  // every tile of the unit, instead of every XCD streaming every unit from the Infinity Cache.
+  const int tiles = a.na_tiles * a.nb_tiles;
+  int g, split, tile;
+  {
+    const int L = blockIdx.x, xcd = L & 7, k = L >> 3;
+    const int j = k / tiles;
+    tile = k - j * tiles;
+    const int u = j * 8 + xcd;
+    if (u >= a.groups * a.splitk) return;               // whole workgroup: idle filler of the last unit row
+    g = u / a.splitk; split = u - g * a.splitk;
+  }
+  const int a_tile = tile % a.na_tiles, b_tile = tile / a.na_tiles;
+  const int QQ = a.Qh * a.Qw;
+  const unsigned OOB = 0x80000000u;
+
+  // DMA geometry: piece = 4 rows x 256 B; wave w, instruction i (0,1) stages rows (4i + w)*4 .. +3 of each operand
+  const int lrow = lane >> 4, pc = lane & 15;
+  const int swz = (lrow << 2) | (wave & 3);           // ((row & 3) << 2) | ((row >> 2) & 3) for row = (4i+w)*4 + lrow
+  const int c = pc ^ swz;                             // logical 16-byte chunk this lane fetches
+  const int a_ch = a_tile * BT + c * 8;
+  const bool a_ok = a_ch < a.Ca;
+  const int nb = b_tile * BT + c * 8;
+  const bool b_ok = nb < a.NB;
+  int bt = 0, bc = 0;
+  if (b_ok) { bt = nb / a.Cb; bc = nb - bt * a.Cb; }
+  const int ti = a.tap[bt];
+  const int tdy = (int)(signed char)(ti & 0xff), tdx = (int)(signed char)((ti >> 8) & 0xff);
+  const T* Ag = (const T*)a.A + (size_t)g * a.a_gstride;
+  const T* Bg = (const T*)a.B + (size_t)g * a.b_gstride;
+  __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)Ag, 0, a.a_bytes - (unsigned)g * (unsigned)a.a_gstride * 2u, 0x00020000);
+  __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc((void*)Bg, 0, a.b_bytes - (unsigned)g * (unsigned)a.b_gstride * 2u, 0x00020000);
+
+  const int step0 = split * a.steps_per_split;
+  int nsteps = a.steps_per_split;
+  {
+    int total = (a.M + BKP - 1) / BKP;
+    if (step0 + nsteps > total) nsteps = total - step0;
+  }
+  if (nsteps <= 0) return;
+
+  int pm[NP], pn[NP], py[NP], px[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    int m = step0 * BKP + (4 * i + wave) * 4 + lrow;
+    pm[i] = m;
+    int n = m / QQ, rr = m - n * QQ, qy = rr / a.Qw, qx = rr - qy * a.Qw;
+    pn[i] = n; py[i] = qy; px[i] = qx;
+  }
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  auto issue = [&](int buf) {
+    char* base = smem + buf * 2 * TILE + wave * (4 * RS);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const bool mok = pm[i] < a.M;
+      unsigned ao = (mok && a_ok) ? (unsigned)((pm[i] * a.a_pitch + a_ch) * 2) : OOB;
+      int iy = py[i] * a.istride + tdy, ix = px[i] * a.istride + tdx;
+      if (a.reflect) {
+        iy = iy < 0 ? -iy : (iy >= a.Hi ? 2 * a.Hi - 2 - iy : iy);
+        ix = ix < 0 ? -ix : (ix >= a.Wi ? 2 * a.Wi - 2 - ix : ix);
+      }
+      const bool bok = mok && b_ok && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi;
+      unsigned bo = bok ? (unsigned)((((pn[i] * a.Hi + iy) * a.Wi + ix) * a.b_pitch + bc) * 2) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ar, (lds_ptr)(base + i * (16 * RS)), 16, (int)ao, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(br, (lds_ptr)(base + TILE + i * (16 * RS)), 16, (int)bo, 0, 0, 0);
+      pm[i] += BKP; px[i] += BKP;
+      while (px[i] >= a.Qw) { px[i] -= a.Qw; if (++py[i] >= a.Qh) { py[i] = 0; ++pn[i]; } }
+    }
+  };
+
+  f32x16 acc[TT][TT];
+  f32x16 accb[TT];
+#pragma unroll
+  for (int i = 0; i < TT; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accb[i][e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < TT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  }
+  const int wa0 = (wave >> 1) * (TT * 32), wb0 = (wave & 1) * (TT * 32);
+  const bool do_bias = a.db != nullptr && b_tile == 0 && wb0 == 0;          // wave-uniform
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 ones_s = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};   // bf16 1.0
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
+
+  // transposed-read lane geometry (see wgrad_kernel): group gq = lane>>4 -> channel block 16*(gq&1), k half gq>>1
+  const int gq = lane >> 4, gg = gq & 1, hh = gq >> 1, q = (lane >> 2) & 3, p = lane & 3;
+
+  issue(0);
+  __syncthreads();
+  for (int kt = 0; kt < nsteps; ++kt) {
+    if (kt + 1 < nsteps && a.diag != 1) issue((kt + 1) & 1);
+    const char* At = smem + (kt & 1) * 2 * TILE;
+    const char* Bt = At + TILE;
+    if (a.diag != 2)
+#pragma unroll
+    for (int s = 0; s < BKP / 16; ++s) {
+      s16x4 av[2][TT], bv[2][TT];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int row = s * 16 + 8 * hh + q + 4 * half;
+        const int rs = ((row & 3) << 2) | ((row >> 2) & 3);
+        const char* ra = At + row * RS + 8 * (p & 1);
+        const char* rb = Bt + row * RS + 8 * (p & 1);
+#pragma unroll
+        for (int i = 0; i < TT; ++i) {
+          const int c0 = (wa0 + 32 * i + 16 * gg) / 8 + (p >> 1);
+          av[half][i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ra + 16 * (c0 ^ rs)));
+        }
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+          const int c0 = (wb0 + 32 * j + 16 * gg) / 8 + (p >> 1);
+          bv[half][j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(rb + 16 * (c0 ^ rs)));
+        }
+      }
+      bf16x8 af[TT], bf[TT];
+#pragma unroll
+      for (int i = 0; i < TT; ++i) {
+        s16x8 t = {av[0][i][0], av[0][i][1], av[0][i][2], av[0][i][3], av[1][i][0], av[1][i][1], av[1][i][2], av[1][i][3]};
+        af[i] = __builtin_bit_cast(bf16x8, t);
+        s16x8 u = {bv[0][i][0], bv[0][i][1], bv[0][i][2], bv[0][i][3], bv[1][i][0], bv[1][i][1], bv[1][i][2], bv[1][i][3]};
+        bf[i] = __builtin_bit_cast(bf16x8, u);
+      }
+#pragma unroll
+      for (int i = 0; i < TT; ++i)
+#pragma unroll
+        for (int j = 0; j < TT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < TT; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], ones, accb[i], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  const int r = lane & 31, h = lane >> 5;
+  float* dWg = a.dW + (size_t)g * a.dw_gstride;
+  if (a.diag == 3) return;
+#pragma unroll
+  for (int j = 0; j < TT; ++j) {
+    int n = b_tile * BT + wb0 + 32 * j + r;
+    if (n >= a.NB) continue;
+    int t = n / a.Cb, cch = n - t * a.Cb;
+    if (cch >= a.Cb_real) continue;
+    int col = t * a.Cb_real + cch;
+#pragma unroll
+    for (int i = 0; i < TT; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int arow = a_tile * BT + wa0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (arow < a.Ca_real) atomicAdd(dWg + (size_t)arow * a.dw_row + col, acc[i][j][e]);
+      }
+  }
+  if (do_bias && r == 0) {
+    float* dbg = a.db + (size_t)g * a.Ca_real;
+#pragma unroll
+    for (int i = 0; i < TT; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int arow = a_tile * BT + wa0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (arow < a.Ca_real) atomicAdd(dbg + arow, accb[i][e]);
+      }
+  }
+}
+
+extern "C" int s2p_conv2d_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, float* db,
                                 int cin_real, int cout_real, int64_t dw_gstride, int splitk, void* stream) {
   if (!d || !x || !dy || !dw) S2P_FAIL(-1, "s2p_conv2d_wgrad: null pointer");
   if (d->dtype != S2P_F32 && d->dtype != S2P_BF16) S2P_FAIL(-1, "s2p_conv2d_wgrad: bad dtype");
@@ -200,9 +390,13 @@ extern "C" int s2p_conv2d_wgrad(const s2p_conv_desc* d, const void* x, const voi
   if (T > 64) S2P_FAIL(-2, "s2p_conv2d_wgrad: more than 64 taps");
   const int cout_pad = (d->Cout + ce - 1) / ce * ce;
   if (cout_pad > d->y_pitch) S2P_FAIL(-1, "s2p_conv2d_wgrad: dy pitch < padded Cout");
-  if (s2p_thin_applicable(d) && cout_real == d->Cout) return s2p_thin_wgrad(d, x, dy, dw, cin_real, (hipStream_t)stream);
+  if (db && d->transposed) S2P_FAIL(-1, "s2p_conv2d_wgrad: bias gradient is undefined for the transposed form");
+  if (s2p_thin_applicable(d) && cout_real == d->Cout) {
+    if (db) { int rc = s2p_channel_sum(d->dtype, dy, (int64_t)d->N * d->Ho * d->Wo, cout_real, d->y_pitch, db, stream); if (rc) return rc; }
+    return s2p_thin_wgrad(d, x, dy, dw, cin_real, (hipStream_t)stream);
+  }
   WgradArgs a{};
-  a.dW = dw;
+  a.dW = dw; a.db = nullptr;
   a.istride = d->stride; a.reflect = d->reflect; a.T = T;
   if (!d->transposed) {        // A = dY on the output grid, B = X gathered
     a.A = dy; a.B = x;
@@ -234,8 +428,37 @@ extern "C" int s2p_conv2d_wgrad(const s2p_conv_desc* d, const void* x, const voi
   a.splitk = cdiv(total_steps, a.steps_per_split);
   dim3 grid(a.na_tiles * a.nb_tiles, d->groups, a.splitk);
   hipStream_t st = (hipStream_t)stream;
-  if (d->dtype == S2P_F32) hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(wgrad_kernel<__bf16>, grid, dim3(256), 0, st, a);
+  const long long abytes = (long long)d->N * a.Qh * a.Qw * a.a_pitch * 2, bbytes = (long long)d->N * a.Hi * a.Wi * a.b_pitch * 2;
+  static const int no_dma = getenv("S2P_NO_LDS_DMA") ? 1 : 0;
+  // LDS-DMA staging pays for dense operands; for large-pitch (grouped / channel-sliced) operands the register-staged
+  // kernel measured faster on MI355X (658 vs 930 us on the 12-group gamma/beta wgrad), so it keeps that path.
+  const bool dense = a.a_pitch <= 1024 && a.b_pitch <= 1024;
+  if (d->dtype == S2P_BF16 && !no_dma && dense && abytes < (1ll << 31) && bbytes < (1ll << 31)) {
+    a.a_bytes = (unsigned)abytes; a.b_bytes = (unsigned)bbytes;
+    static const int diag = getenv("S2P_DIAG") ? atoi(getenv("S2P_DIAG")) : 0;
+    a.diag = diag;
+    a.db = db;                                  // fused bias gradient (groups: db is [groups][Cout])
+    static const int target = getenv("S2P_WGRAD_BLOCKS") ? atoi(getenv("S2P_WGRAD_BLOCKS")) : 384;
+    // split count: (groups * splits) a multiple of 8 (one unit per XCD per round), enough workgroups to fill the chip
+    const int tiles = a.na_tiles * a.nb_tiles;
+    const int total = cdiv(a.M, 32);
+    int U = 8 * (cdiv(target, tiles * 8) > 1 ? cdiv(target, tiles * 8) : 1);
+    int sk = cdiv(U, d->groups);
+    if (sk > total) sk = total;
+    if (sk < 1) sk = 1;
+    a.steps_per_split = cdiv(total, sk); a.splitk = cdiv(total, a.steps_per_split);
+    a.groups = d->groups;
+    const int units = a.groups * a.splitk;
+    dim3 grid1(8 * tiles * cdiv(units, 8));
+    hipLaunchKernelGGL(wgrad_dma_kernel<32>, grid1, dim3(256), 0, st, a);
+  } else {
+    if (db) {
+      int rc = s2p_channel_sum(d->dtype, dy, (int64_t)d->N * d->Ho * d->Wo, cout_real * d->groups, d->y_pitch, db, stream);
+      if (rc) return rc;
+    }
+    if (d->dtype == S2P_F32) hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(wgrad_kernel<__bf16>, grid, dim3(256), 0, st, a);
+  }
   S2P_CHECK_LAUNCH("wgrad_kernel");
   return 0;
 }

@@ -72,11 +72,12 @@ def _build_d_input(model, fake_nhwc, prev_image, real_image):
 
 
 def _hinge_seed(logits, mode_lo, mode_hi, N, num_D, loss_lo, loss_hi):
-    """logits: NHWC [2N,h,w,ce] (1 real channel).  Applies hinge mode_lo to the first N samples and mode_hi (or
-    nothing if None) to the last N; returns the gradient in the layout of `logits`."""
+    """logits: NHWC [2N,h,w,ce] (1 real channel).  Applies hinge mode_lo to the first N samples and mode_hi to the
+    last N (if not None); returns the gradient in the layout of `logits` ([N,...] only when mode_hi is None)."""
     B, h, w, ce = logits.shape
-    dense = ops.nhwc_to_nchw(logits, 1)                     # [2N,1,h,w] fp32
-    gd = torch.zeros_like(dense)
+    keep = B if mode_hi is not None else N
+    dense = ops.nhwc_to_nchw(logits[:keep], 1)              # [keep,1,h,w] fp32
+    gd = torch.empty_like(dense)
     cnt = N * h * w
     sc = 1.0 / (cnt * num_D)
     ops.hinge_loss(dense, cnt, mode_lo, sc, loss_lo, gd, x_off=0)
@@ -104,9 +105,9 @@ class _GLossNode(torch.autograd.Function):
             if not opt.no_ganFeat_loss:
                 for j in range(len(feats) - 1):
                     f = feats[j]
-                    gf = torch.zeros_like(f)
+                    gf = torch.empty_like(f[:N])             # gradient of the fake half only (real half: detached)
                     half = f[:N].numel()
-                    ops.l1_loss(f[:N], f[N:], opt.lambda_feat / num_D / half, losses[1:2], gf[:N])
+                    ops.l1_loss(f[:N], f[N:], opt.lambda_feat / num_D / half, losses[1:2], gf)
                     g[j] = gf
             grads.append(g)
         # pixel L1 + VGG share the NHWC copy of the real image
@@ -144,7 +145,7 @@ class _GLossNode(torch.autograd.Function):
                     ops.scale_(t, g[2:3])
             ops.scale_(ctx.d_fake, g[3:4])
         d_fake = ctx.d_fake
-        dx = model.netD.bwd_nhwc(ctx.dctx, ctx.grads, need_wgrad=False, need_dx=True)
+        dx = model.netD.bwd_nhwc(ctx.dctx, ctx.grads, need_wgrad=False, need_dx=True, n_keep=N)   # fake half only
         ops.copy_channels(dx, 3, d_fake, 0, 3, accumulate=True, src_rows=N)
         if ctx.vctx is not None:
             dv = model.vgg.bwd_nhwc(ctx.vctx, ctx.tap_grads, N)

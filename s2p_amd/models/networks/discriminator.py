@@ -71,9 +71,13 @@ class NLayerDiscriminator(BaseNetwork):
         saved.append((f, None, None, out))
         return feats, saved
 
-    def bwd_nhwc(self, saved, grads, need_wgrad=True, need_dx=True):
-        """grads[j] = d(loss)/d(feature j) or None.  Returns d(loss)/dx (or None)."""
+    def bwd_nhwc(self, saved, grads, need_wgrad=True, need_dx=True, n_keep=None):
+        """grads[j] = d(loss)/d(feature j) or None.  Returns d(loss)/dx (or None).  With `n_keep`, only the first
+        n_keep samples are differentiated (InstanceNorm is per-sample, so a batch prefix is self-contained): the G step
+        uses it because the real half of the D batch carries no gradient."""
         nl = self.n_layers
+        if n_keep is not None:
+            saved = [tuple(None if t is None else t[:n_keep] for t in tup) for tup in saved]
         xin, _, _, out = saved[nl]
         g = grads[nl]
         if g is None:
@@ -142,11 +146,13 @@ class MultiscaleDiscriminator(BaseNetwork):
                 x = ops.avgpool_fwd(x)
         return result, ctx
 
-    def bwd_nhwc(self, ctx, grads, need_wgrad=True, need_dx=True):
+    def bwd_nhwc(self, ctx, grads, need_wgrad=True, need_dx=True, n_keep=None):
         dx_next = None
         for i in reversed(range(self.num_D)):
             x, saved = ctx[i]
-            dx = self.subnets()[i].bwd_nhwc(saved, grads[i], need_wgrad=need_wgrad, need_dx=need_dx)
+            if n_keep is not None:
+                x = x[:n_keep]
+            dx = self.subnets()[i].bwd_nhwc(saved, grads[i], need_wgrad=need_wgrad, need_dx=need_dx, n_keep=n_keep)
             if need_dx:
                 if dx_next is not None:
                     ops.avgpool_bwd(dx_next, tuple(x.shape), dx=dx, accumulate=True)

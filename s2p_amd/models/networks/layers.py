@@ -30,9 +30,7 @@ class ConvLayer:
     def wgrad(self, x, dy):
         """Accumulate weight (and bias) gradients straight into the flat grad buffer."""
         ops.conv_wgrad(self.geom, x, dy, self.pk.gw, self.cin_pad(x.dtype), self.cin_real, self.cout_real,
-                       dw_gstride=self.pk.gw_gstride)
-        if self.pk.gb is not None:
-            ops.channel_sum(dy, self.pk.gb.numel(), self.pk.gb)
+                       dw_gstride=self.pk.gw_gstride, db=self.pk.gb)      # bias gradient fused into the wgrad pass
 
 
 def make_conv_param(cout, cin, k):

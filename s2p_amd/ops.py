@@ -116,12 +116,12 @@ def conv_dgrad(geom, dy, w_bwd, x_shape, cin_pad, aux=None, epi=EPI_STORE, aux_a
     return dx
 
 
-def conv_wgrad(geom, x, dy, dw, cin_pad, cin_real, cout_real, dw_gstride=0, splitk=0):
+def conv_wgrad(geom, x, dy, dw, cin_pad, cin_real, cout_real, dw_gstride=0, splitk=0, db=None):
     """dw += wgrad (cudnn_convolution_backward_weight equivalent); dw is an fp32 view in channels-last layout."""
     N, H, W, xp = x.shape
     d = geom.desc(x.dtype, N, H, W, cin_pad, xp, dy.shape[3])
     pr = _Prof("wgrad", geom, N, H, W, x.dtype)
-    check(lib().s2p_conv2d_wgrad(ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), cin_real, cout_real, dw_gstride, splitk,
+    check(lib().s2p_conv2d_wgrad(ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db), cin_real, cout_real, dw_gstride, splitk,
                                  stream()), "s2p_conv2d_wgrad")
     pr.done()
 

@@ -103,13 +103,16 @@ def test_conv_fwd_dgrad_wgrad(hip_device, dtype, case):
     # wgrad -> channels-last fp32 [rows][T][cols]
     rows, cols = (cin, cout) if tr else (cout, cin)
     dw = torch.zeros(rows, k * k, cols, device=dev)
-    ops.conv_wgrad(geom, xd, dyd, dw, cin_pad, cin, cout)
+    dbf = None if tr else torch.zeros(cout, device=dev)          # bias gradient fused into the wgrad pass
+    ops.conv_wgrad(geom, xd, dyd, dw, cin_pad, cin, cout, db=dbf)
     torch.cuda.synchronize()
     dw_ref = wr.grad.permute(0, 2, 3, 1).reshape(rows, k * k, cols)
     assert rel_err(dw.cpu(), dw_ref) < TOL[dtype]
     db = torch.zeros(cout, device=dev)
     ops.channel_sum(dyd, cout, db)
     assert rel_err(db.cpu(), dy.sum((0, 2, 3))) < TOL[dtype]
+    if dbf is not None:
+        assert rel_err(dbf.cpu(), dy.sum((0, 2, 3))) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -143,8 +146,10 @@ def test_conv_groups_epilogues(hip_device, dtype):
     torch.cuda.synchronize()
     assert rel_err(nchw(dx, G * cin), xr.grad) < TOL[dtype]
     dw = torch.zeros(G, cout, 9, cin, device=dev)
-    ops.conv_wgrad(geom, xd, dpre, dw, cin, cin, cout, dw_gstride=cout * 9 * cin)
+    dbg = torch.zeros(G * cout, device=dev)
+    ops.conv_wgrad(geom, xd, dpre, dw, cin, cin, cout, dw_gstride=cout * 9 * cin, db=dbg)
     torch.cuda.synchronize()
+    assert rel_err(dbg.cpu(), nchw(dpre, G * cout).sum((0, 2, 3))) < TOL[dtype]
     assert rel_err(dw.cpu().reshape(G * cout, 9, cin), wr.grad.permute(0, 2, 3, 1).reshape(G * cout, 9, cin)) < TOL[dtype]
     # residual epilogue and fused producer-activation gradient epilogue
     geom1 = ops.ConvGeom(G * cin, G * cin, 3, 1, 1)
