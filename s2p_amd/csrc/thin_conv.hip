@@ -130,6 +130,11 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinArgs a) {
   }
 }
 
+static bool tiled_applicable(const s2p_conv_desc* d);
+int s2p_thin_tiled_fwd(const s2p_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int act,
+                       float slope, hipStream_t st);
+int s2p_thin_tiled_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, int cin_real, hipStream_t st);
+
 static void fill_args(ThinArgs& a, const s2p_conv_desc* d) {
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.x_pitch = d->x_pitch; a.Ho = d->Ho; a.Wo = d->Wo;
   a.Cout = d->Cout; a.y_pitch = d->y_pitch; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
@@ -143,6 +148,7 @@ bool s2p_thin_applicable(const s2p_conv_desc* d) {
 
 int s2p_thin_fwd(const s2p_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int act, float slope,
                  hipStream_t st) {
+  if (tiled_applicable(d)) return s2p_thin_tiled_fwd(d, x, w, bias, y, act, slope, st);
   ThinArgs a{};
   fill_args(a, d);
   a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = bias; a.y = (__bf16*)y; a.act = act; a.slope = slope;
@@ -163,6 +169,7 @@ int s2p_thin_fwd(const s2p_conv_desc* d, const void* x, const void* w, const flo
 }
 
 int s2p_thin_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, int cin_real, hipStream_t st) {
+  if (tiled_applicable(d)) return s2p_thin_tiled_wgrad(d, x, dy, dw, cin_real, st);
   ThinArgs a{};
   fill_args(a, d);
   a.x = (const __bf16*)x; a.dy = (const __bf16*)dy; a.dw = dw; a.cin_real = cin_real;
@@ -172,5 +179,268 @@ int s2p_thin_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float*
   a.rows_per_block = cdiv(a.M, gy); gy = cdiv(a.M, a.rows_per_block);
   hipLaunchKernelGGL(thin_wgrad_kernel, dim3(gx, gy), dim3(256), 0, st, a);
   S2P_CHECK_LAUNCH("thin_wgrad_kernel");
+  return 0;
+}
+
+// ================================================================================================
+// Spatially tiled MFMA kernels for thin-Cout, large-kernel, stride-1 convs (the generator's 7x7 64->3 output
+// conv at 84x84 .. 256x256).  A workgroup owns a 16x8 output tile of one image and stages the input halo tile
+// ((16+K-1) x (8+K-1) positions x Cin) ONCE in LDS; all K*K taps then read LDS, so the 49-fold re-read of the
+// activation that an implicit GEMM does through L2 disappears.  The contraction runs on v_mfma_f32_16x16x32_bf16
+// with the thin dimension (Cout <= 4, padded to 16) as one MFMA side: even at 3/16 utilisation the matrix core
+// is ~8x faster than the packed-VALU direct form.
+//   fwd  : D[pixel][co]  = sum_{tap,ci} X[pixel+tap][ci] * W[co][tap][ci]      A = halo rows (b128 reads), B = W
+//   wgrad: D[co][ci]@tap = sum_pixel  dY[pixel][co] * X[pixel+tap][ci]        A = dY^T (LDS [co][pixel]),
+//                                                                              B = halo via ds_read_b64_tr_b16
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+constexpr int TW = 16, TH = 8;
+
+struct TileArgs {
+  const __bf16* x; const __bf16* w; const float* bias; const __bf16* dy; __bf16* y; float* dw;
+  int N, H, W, Cin, x_pitch, Ho, Wo, Cout, y_pitch, K, pad, reflect, act;
+  float slope;
+  int cin_real, tiles_x, tiles_y, ntiles;
+};
+
+// Halo tile -> LDS.  All global loads of a thread are issued before the first LDS store (up to MAXL 16-byte loads in
+// flight per thread) so the phase costs about one memory latency instead of one per chunk.
+template <int MAXL>
+__device__ __forceinline__ void load_halo(const TileArgs& a, char* xt, int xs, int n, int oy0, int ox0, int HW_, int HH) {
+  const int nch = a.Cin / 8;
+  const int total = HW_ * HH * nch;
+  u32x4 v[MAXL];
+  int dst[MAXL];
+#pragma unroll
+  for (int i = 0; i < MAXL; ++i) {
+    const int idx = threadIdx.x + i * blockDim.x;
+    v[i] = (u32x4){0u, 0u, 0u, 0u};
+    dst[i] = -1;
+    if (idx < total) {
+      int pos = idx / nch, ch = idx - pos * nch;
+      int hy = pos / HW_, hx = pos - hy * HW_;
+      int iy = oy0 + hy - a.pad, ix = ox0 + hx - a.pad;
+      bool ok = true;
+      if (a.reflect) {
+        iy = iy < 0 ? -iy : (iy >= a.H ? 2 * a.H - 2 - iy : iy);
+        ix = ix < 0 ? -ix : (ix >= a.W ? 2 * a.W - 2 - ix : ix);
+        iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);        // positions that belong to clipped edge-tile pixels
+        ix = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
+      } else {
+        ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      }
+      if (ok) v[i] = *(const u32x4*)(a.x + (((size_t)n * a.H + iy) * a.W + ix) * a.x_pitch + ch * 8);
+      dst[i] = pos * xs + ch * 16;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXL; ++i)
+    if (dst[i] >= 0) *(u32x4*)(xt + dst[i]) = v[i];
+  // tiles larger than MAXL * blockDim chunks (not reached by the shapes admitted in tiled_applicable)
+  for (int idx = threadIdx.x + MAXL * blockDim.x; idx < total; idx += blockDim.x) {
+    int pos = idx / nch, ch = idx - pos * nch;
+    int hy = pos / HW_, hx = pos - hy * HW_;
+    int iy = oy0 + hy - a.pad, ix = ox0 + hx - a.pad;
+    bool ok = true;
+    if (a.reflect) {
+      iy = iy < 0 ? -iy : (iy >= a.H ? 2 * a.H - 2 - iy : iy);
+      ix = ix < 0 ? -ix : (ix >= a.W ? 2 * a.W - 2 - ix : ix);
+      iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);
+      ix = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
+    } else {
+      ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    }
+    u32x4 t = {0u, 0u, 0u, 0u};
+    if (ok) t = *(const u32x4*)(a.x + (((size_t)n * a.H + iy) * a.W + ix) * a.x_pitch + ch * 8);
+    *(u32x4*)(xt + pos * xs + ch * 16) = t;
+  }
+}
+
+// register-lean variant (one chunk in flight per thread): the wgrad kernel has no VGPRs to spare for staging
+__device__ __forceinline__ void load_halo_simple(const TileArgs& a, char* xt, int xs, int n, int oy0, int ox0, int HW_, int HH) {
+  const int nch = a.Cin / 8;
+  for (int idx = threadIdx.x; idx < HW_ * HH * nch; idx += blockDim.x) {
+    int pos = idx / nch, ch = idx - pos * nch;
+    int hy = pos / HW_, hx = pos - hy * HW_;
+    int iy = oy0 + hy - a.pad, ix = ox0 + hx - a.pad;
+    bool ok = true;
+    if (a.reflect) {
+      iy = iy < 0 ? -iy : (iy >= a.H ? 2 * a.H - 2 - iy : iy);
+      ix = ix < 0 ? -ix : (ix >= a.W ? 2 * a.W - 2 - ix : ix);
+      iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);
+      ix = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
+    } else {
+      ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    }
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (ok) v = *(const u32x4*)(a.x + (((size_t)n * a.H + iy) * a.W + ix) * a.x_pitch + ch * 8);
+    *(u32x4*)(xt + pos * xs + ch * 16) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void thin_tiled_fwd_kernel(const TileArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int T = a.K * a.K, HW_ = TW + a.K - 1, HH = TH + a.K - 1;
+  const int xs = a.Cin * 2 + 16;                         // halo position stride (padded: conflict-free b128 reads)
+  char* xt = smem;
+  char* wt = xt + HW_ * HH * xs;                         // [Cout][T][Cin] bf16
+  char* ot = wt + a.Cout * T * a.Cin * 2;                // [128 pixels][8] bf16 output staging
+  const int tile = blockIdx.x;
+  const int n = tile / (a.tiles_x * a.tiles_y), tr = tile - n * a.tiles_x * a.tiles_y;
+  const int oy0 = (tr / a.tiles_x) * TH, ox0 = (tr % a.tiles_x) * TW;
+  const int wbytes = a.Cout * T * a.Cin * 2;
+  for (int i = threadIdx.x * 16; i < wbytes; i += 256 * 16) *(u32x4*)(wt + i) = *(const u32x4*)((const char*)a.w + i);
+  for (int i = threadIdx.x * 16; i < TW * TH * 16; i += 256 * 16) *(u32x4*)(ot + i) = (u32x4){0u, 0u, 0u, 0u};
+  load_halo<10>(a, xt, xs, n, oy0, ox0, HW_, HH);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, kg = lane >> 4;             // A: pixel row l15, k group kg ; B: column (co) l15
+  f32x4_t acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  const bf16x8 zero8 = {};
+  const int nck = a.Cin / 32;
+  for (int ky = 0; ky < a.K; ++ky)
+    for (int kx = 0; kx < a.K; ++kx) {
+      const int t = ky * a.K + kx;
+      for (int ck = 0; ck < nck; ++ck) {
+        bf16x8 bfrag = zero8;
+        if (l15 < a.Cout) bfrag = *(const bf16x8*)(wt + ((l15 * T + t) * a.Cin + ck * 32 + kg * 8) * 2);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          const int ry = wave * 2 + rr;
+          const bf16x8 afrag = *(const bf16x8*)(xt + ((ry + ky) * HW_ + l15 + kx) * xs + (ck * 32 + kg * 8) * 2);
+          acc[rr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, bfrag, acc[rr], 0, 0, 0);
+        }
+      }
+    }
+  // D: col = lane & 15 (co), row = (lane >> 4) * 4 + reg (pixel within the 16-pixel tile row)
+  if (l15 < a.Cout) {
+    const float b = a.bias ? a.bias[l15] : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int pix = (wave * 2 + rr) * TW + kg * 4 + e;
+        *(__bf16*)(ot + pix * 16 + l15 * 2) = (__bf16)act_fwd(acc[rr][e] + b, a.act, a.slope);
+      }
+  }
+  __syncthreads();
+  if (threadIdx.x < TW * TH) {
+    int ry = threadIdx.x / TW, rx = threadIdx.x - ry * TW;
+    int oy = oy0 + ry, ox = ox0 + rx;
+    if (oy < a.Ho && ox < a.Wo)
+      *(u32x4*)(a.y + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.y_pitch) = *(const u32x4*)(ot + threadIdx.x * 16);
+  }
+}
+
+// 512 threads (8 waves); persistent over tiles; each wave owns (tap, 16-channel group) pairs w, w+8, ...
+template <int MAXP>
+__global__ __launch_bounds__(512) void thin_tiled_wgrad_kernel(const TileArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int T = a.K * a.K, HW_ = TW + a.K - 1, HH = TH + a.K - 1;
+  const int xs = a.Cin * 2 + 16;
+  char* xt = smem;
+  char* dyt = xt + HW_ * HH * xs;                        // [4 co][128 pixels] bf16, transposed dY tile
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, kg = lane >> 4;
+  const int q = (lane >> 2) & 3, p = lane & 3;           // transposed-read lane roles inside the 16-lane group
+  const int ncg = a.Cin / 16, npairs = T * ncg;
+  f32x4_t acc[MAXP];
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const bf16x8 zero8 = {};
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int n = tile / (a.tiles_x * a.tiles_y), tr = tile - n * a.tiles_x * a.tiles_y;
+    const int oy0 = (tr / a.tiles_x) * TH, ox0 = (tr % a.tiles_x) * TW;
+    __syncthreads();                                     // previous tile fully consumed
+    load_halo_simple(a, xt, xs, n, oy0, ox0, HW_, HH);
+    if (threadIdx.x < TW * TH) {
+      int ry = threadIdx.x / TW, rx = threadIdx.x - ry * TW;
+      int oy = oy0 + ry, ox = ox0 + rx;
+      Chunk<__bf16> d; d.raw = (u32x4){0u, 0u, 0u, 0u};
+      if (oy < a.Ho && ox < a.Wo) d.raw = *(const u32x4*)(a.dy + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.y_pitch);
+#pragma unroll
+      for (int co = 0; co < 4; ++co) *(unsigned short*)(dyt + (co * TW * TH + threadIdx.x) * 2) = (unsigned short)((d.raw[co >> 1] >> ((co & 1) * 16)) & 0xffff);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {                     // 4 x 32 pixels = two tile rows each
+      bf16x8 afrag = zero8;                              // A[row = co][k = 8*kg + j] = dY[pixel 32*kk + 8*kg + j][co]
+      if (l15 < a.Cout) afrag = *(const bf16x8*)(dyt + (l15 * TW * TH + 32 * kk + 8 * kg) * 2);
+      // this lane group's 8 pixels: tile row ry = 2*kk + (kg >> 1), columns 8*(kg & 1) .. +7
+      const int ry = 2 * kk + (kg >> 1), px0 = 8 * (kg & 1);
+#pragma unroll
+      for (int i = 0; i < MAXP; ++i) {
+        const int pr = wave + 8 * i;
+        if (pr < npairs) {                                // wave-uniform
+          const int t = pr / ncg, cg = pr - t * ncg;
+          const int ky = t / a.K, kx = t - ky * a.K;
+          const char* base = xt + ((ry + ky) * HW_ + px0 + kx + q) * xs + (cg * 16 + 4 * p) * 2;
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * xs));
+          s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, __builtin_bit_cast(bf16x8, v), acc[i], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // D: col = lane & 15 (ci within the group), row = (lane >> 4) * 4 + reg (co): rows < Cout live in lanes 0..15
+  if (kg == 0) {
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      const int pr = wave + 8 * i;
+      if (pr < npairs) {
+        const int t = pr / ncg, cg = pr - t * ncg;
+        const int ci = cg * 16 + l15;
+        if (ci < a.cin_real)
+#pragma unroll
+          for (int co = 0; co < 4; ++co)
+            if (co < a.Cout) atomicAdd(a.dw + ((size_t)co * T + t) * a.cin_real + ci, acc[i][co]);
+      }
+    }
+  }
+}
+
+static bool tiled_applicable(const s2p_conv_desc* d) {
+  if (!(d->dtype == S2P_BF16 && d->groups == 1 && !d->transposed && d->Cout <= 4 && d->stride == 1 && d->KH == d->KW &&
+        d->KH >= 3 && d->KH <= 7 && d->Cin % 32 == 0 && d->Cin <= 128 && d->y_pitch == 8 && d->x_pitch == d->Cin))
+    return false;
+  const int HW_ = TW + d->KH - 1, HH = TH + d->KH - 1;
+  const long long lds = (long long)HW_ * HH * (d->Cin * 2 + 16) + (long long)d->Cout * d->KH * d->KW * d->Cin * 2 + TW * TH * 16;
+  const int pairs = d->KH * d->KW * (d->Cin / 16);
+  return lds <= 64 * 1024 && pairs <= 8 * 32 && d->Ho * d->Wo >= 1024;
+}
+
+static void fill_tile_args(TileArgs& a, const s2p_conv_desc* d) {
+  a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.x_pitch = d->x_pitch; a.Ho = d->Ho; a.Wo = d->Wo;
+  a.Cout = d->Cout; a.y_pitch = d->y_pitch; a.K = d->KH; a.pad = d->pad; a.reflect = d->reflect;
+  a.tiles_x = cdiv(d->Wo, TW); a.tiles_y = cdiv(d->Ho, TH); a.ntiles = d->N * a.tiles_x * a.tiles_y;
+}
+
+int s2p_thin_tiled_fwd(const s2p_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int act,
+                       float slope, hipStream_t st) {
+  TileArgs a{};
+  fill_tile_args(a, d);
+  a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = bias; a.y = (__bf16*)y; a.act = act; a.slope = slope;
+  const int HW_ = TW + d->KH - 1, HH = TH + d->KH - 1;
+  const size_t lds = (size_t)HW_ * HH * (d->Cin * 2 + 16) + (size_t)d->Cout * d->KH * d->KW * d->Cin * 2 + TW * TH * 16;
+  hipLaunchKernelGGL(thin_tiled_fwd_kernel, dim3(a.ntiles), dim3(256), lds, st, a);
+  S2P_CHECK_LAUNCH("thin_tiled_fwd_kernel");
+  return 0;
+}
+
+int s2p_thin_tiled_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, int cin_real, hipStream_t st) {
+  TileArgs a{};
+  fill_tile_args(a, d);
+  a.x = (const __bf16*)x; a.dy = (const __bf16*)dy; a.dw = dw; a.cin_real = cin_real;
+  const int HW_ = TW + d->KH - 1, HH = TH + d->KH - 1;
+  const size_t lds = (size_t)HW_ * HH * (d->Cin * 2 + 16) + 4 * TW * TH * 2;
+  const int pairs = d->KH * d->KW * (d->Cin / 16);
+  int blocks = a.ntiles < 512 ? a.ntiles : 512;
+  if (pairs <= 8 * 13) hipLaunchKernelGGL(thin_tiled_wgrad_kernel<13>, dim3(blocks), dim3(512), lds, st, a);
+  else if (pairs <= 8 * 25) hipLaunchKernelGGL(thin_tiled_wgrad_kernel<25>, dim3(blocks), dim3(512), lds, st, a);
+  else hipLaunchKernelGGL(thin_tiled_wgrad_kernel<32>, dim3(blocks), dim3(512), lds, st, a);
+  S2P_CHECK_LAUNCH("thin_tiled_wgrad_kernel");
   return 0;
 }
