@@ -28,6 +28,7 @@ struct GatherArgs {
   int reflect, act, epi, gact;
   float slope, gslope;
   int npix_tiles, nco_tiles;
+  int halo_lo, halo_hi;        // halo kernel: pixels needed before / after the tile in raster order
   int diag;                    // timing-only ablation (S2P_DIAG env): 1 = skip in-loop loads, 2 = skip MFMAs
   int splitk, ksteps;          // generic fp32 path only: split-K over blockIdx.z with fp32 atomics into a zeroed y
   unsigned x_bytes, w_bytes;   // fast path: buffer-descriptor sizes of the gathered tensor / packed weights (per group view)
@@ -609,6 +610,181 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const GatherArgs a) {
   conv_epilogue<T, BCO, BPIX, TCO, TPIX>(a, acc, smem, rowoff, g, co_base, wco0, wpix0, r, h, tid);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Halo-resident variant for stride-1 "same" convolutions (output grid == gathered grid: ResBlk / VGG / gamma-beta
+// convs and their dgrads).  In the implicit GEMM every tap re-fetches a shifted copy of the same pixels from L2
+// (9x for 3x3) and the kernel is bound by L2->LDS bytes.  Here, for each 64-channel slab, the pixel tile PLUS its
+// halo (the contiguous pixel range [tile_start - halo_lo, tile_end + halo_hi) in raster order, which also covers
+// neighbouring rows and images) is staged ONCE and stays resident in LDS while all taps are swept; only the 16 KiB
+// weight stage is streamed per tap.  Per 3x3 slab: 22 + 9*16 KiB instead of 9*32 KiB (-42 % L2 traffic).
+// Tap validity (zero padding, image/row borders) is a per-pixel bit mask; an invalid (pixel, tap) reads a zero row.
+template <int NPOS_CAP, bool DBUF>
+__global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
+  typedef __bf16 T;
+  constexpr int BCO = 128, BPIX = 128, WPIX = 2, TCO = 2, TPIX = 2;
+  constexpr int BK = 64, RS = 128;
+  constexpr int WSTAGE = BCO * RS;                     // 16 KiB weight stage
+  constexpr int HALO = NPOS_CAP * RS;
+  constexpr int ERS = BCO * 2 + 16;
+  constexpr int EPI = BPIX * ERS;
+  constexpr int NHB = DBUF ? 2 : 1;                    // halo buffers (double-buffered when two workgroups still fit a CU)
+  constexpr int MAIN0 = NHB * HALO + 2 * WSTAGE + 1024;      // + zero rows
+  constexpr int MAIN = MAIN0 > EPI ? MAIN0 : EPI;
+  __shared__ __attribute__((aligned(1024))) char smem[MAIN + BPIX * 4];
+  int* rowoff = (int*)(smem + MAIN);
+  char* hbase = smem;
+  char* wbase = smem + NHB * HALO;
+  char* zrow = smem + NHB * HALO + 2 * WSTAGE;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int g = blockIdx.y;
+  int nblk = a.npix_tiles * a.nco_tiles;
+  int bid = blockIdx.x;
+  {
+    int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, k = bid >> 3;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+  }
+  const int co_tile = bid % a.nco_tiles, pix_tile = bid / a.nco_tiles;
+  const int co_base = co_tile * BCO, pix_base = pix_tile * BPIX;
+  const int QQ = a.Qh * a.Qw;
+  if (tid < BPIX) {
+    int m = pix_base + tid;
+    rowoff[tid] = m < a.M ? m : -1;                   // same grid: output pixel index == GEMM pixel index
+  }
+  if (tid < 64) *(u32x4*)(zrow + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
+
+  const unsigned OOB = 0x80000000u;
+  const T* xg = (const T*)a.x + (size_t)g * a.x_gstride;
+  const T* wg = (const T*)a.w + (size_t)g * a.w_gstride;
+  __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, a.x_bytes - (unsigned)g * (unsigned)a.x_gstride * 2u, 0x00020000);
+  __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, a.w_bytes, 0x00020000);
+
+  const int lrow = lane >> 3, pc = lane & 7;
+  // weight DMA: instruction i of wave w stages rows (4i + w)*8 .. +7 of the 128-row stage
+  unsigned w_byte[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int row = (4 * i + wave) * 8 + lrow;
+    int c = pc ^ ((row >> 1) & 7);
+    int co = co_base + row;
+    w_byte[i] = co < a.Cout ? (unsigned)(co * a.w_row * 2 + c * 16) : OOB;
+  }
+  // halo DMA: piece j (8 positions) for j = wave, wave + 4, ...; position p <-> pixel pix_base - halo_lo + p
+  const int npos = BPIX + a.halo_lo + a.halo_hi;
+  constexpr int NHP = (NPOS_CAP / 8 + 3) / 4;
+  unsigned h_byte[NHP];
+#pragma unroll
+  for (int i = 0; i < NHP; ++i) {
+    int pos = (4 * i + wave) * 8 + lrow;
+    int c = pc ^ ((pos >> 1) & 7);
+    long long gpix = (long long)pix_base - a.halo_lo + pos;
+    h_byte[i] = (pos < npos && gpix >= 0 && gpix < a.M) ? (unsigned)(gpix * a.x_pitch * 2 + c * 16) : OOB;
+  }
+  // tap-validity masks of the pixels this lane feeds to the MFMA (B operand columns)
+  const int wco0 = (wave / WPIX) * (TCO * 32);
+  const int wpix0 = (wave % WPIX) * (TPIX * 32);
+  unsigned long long vmask[TPIX];
+#pragma unroll
+  for (int j = 0; j < TPIX; ++j) {
+    int m = pix_base + wpix0 + 32 * j + r;
+    unsigned long long mask = 0ull;
+    if (m < a.M) {
+      int n = m / QQ, rr = m - n * QQ, qy = rr / a.Qw, qx = rr - qy * a.Qw;
+      for (int t = 0; t < a.T; ++t) {
+        int ti = a.tap[t];
+        int iy = qy + (int)(signed char)(ti & 0xff), ix = qx + (int)(signed char)((ti >> 8) & 0xff);
+        if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) mask |= 1ull << t;
+      }
+    }
+    vmask[j] = mask;
+  }
+
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int nslab = a.Cin / BK;
+  const int nk = nslab * a.T;
+
+  auto issue_w = [&](int buf, int tap, int c0) {
+    const int wt = a.tap[tap] >> 16;
+    const int woff = (wt * a.Cin + c0) * 2;
+    char* base = wbase + buf * WSTAGE + wave * (8 * RS);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(base + i * (32 * RS)), 16,
+                                               (int)(w_byte[i] == OOB ? OOB : w_byte[i] + (unsigned)woff), 0, 0, 0);
+  };
+  auto issue_halo = [&](int hb, int c0) {
+    char* base = hbase + hb * HALO + wave * (8 * RS);
+#pragma unroll
+    for (int i = 0; i < NHP; ++i)
+      if ((4 * i + wave) * 8 < npos)                   // wave-uniform
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(base + i * (32 * RS)), 16,
+                                                 (int)(h_byte[i] == OOB ? OOB : h_byte[i] + (unsigned)(c0 * 2)), 0, 0, 0);
+  };
+
+  f32x16 acc[TCO][TPIX];
+#pragma unroll
+  for (int i = 0; i < TCO; ++i)
+#pragma unroll
+    for (int j = 0; j < TPIX; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int swr = (r >> 1) & 7;                        // weight rows: tile bases are multiples of 16 rows
+
+  // one linear pipeline over (slab, tap): weights are always one step ahead; the next slab's halo is prefetched
+  // into the other halo buffer during the current slab (DBUF) or loaded behind a barrier at the slab boundary.
+  issue_halo(0, 0);
+  issue_w(0, 0, 0);
+  __syncthreads();                                     // hipcc drains vmcnt before the barrier
+  int slab = 0, tap = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int c0 = slab * BK;
+    int ntap = tap + 1, nslab_i = slab;
+    if (ntap == a.T) { ntap = 0; ++nslab_i; }
+    if (kt + 1 < nk) issue_w((kt + 1) & 1, ntap, nslab_i * BK);
+    if (DBUF && tap == 0 && slab + 1 < nslab) issue_halo((slab + 1) & 1, c0 + BK);
+    const char* hb = hbase + (DBUF ? (slab & 1) * HALO : 0);
+    const int ti = a.tap[tap];
+    const int toff = (int)(signed char)(ti & 0xff) * a.Wi + (int)(signed char)((ti >> 8) & 0xff);
+    const char* wrow = wbase + (kt & 1) * WSTAGE + (wco0 + r) * RS;
+    const char* prow[TPIX];
+    int psw[TPIX];
+#pragma unroll
+    for (int j = 0; j < TPIX; ++j) {
+      const int hp = wpix0 + 32 * j + r + a.halo_lo + toff;
+      const bool ok = (vmask[j] >> tap) & 1ull;
+      prow[j] = ok ? hb + hp * RS : zrow;
+      psw[j] = ok ? (hp >> 1) & 7 : 0;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf16x8 af[TCO], bf[TPIX];
+#pragma unroll
+      for (int i = 0; i < TCO; ++i) af[i] = *(const bf16x8*)(wrow + i * 32 * RS + (((2 * s + h) ^ swr) * 16));
+#pragma unroll
+      for (int j = 0; j < TPIX; ++j) bf[j] = *(const bf16x8*)(prow[j] + (((2 * s + h) ^ psw[j]) * 16));
+#pragma unroll
+      for (int i = 0; i < TCO; ++i)
+#pragma unroll
+        for (int j = 0; j < TPIX; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    tap = ntap;
+    if (nslab_i != slab) {
+      slab = nslab_i;
+      if (!DBUF && slab < nslab) {                     // single halo buffer: reload it now that nobody reads it
+        issue_halo(0, slab * BK);
+        __syncthreads();
+      }
+    }
+  }
+  (void)nk;
+  conv_epilogue<T, BCO, BPIX, TCO, TPIX>(a, acc, smem, rowoff, g, co_base, wco0, wpix0, r, h, tid);
+}
+
 template <int BCO, int BPIX, int WCO, int WPIX>
 static int launch_fast(GatherArgs& a, int groups, hipStream_t st) {
   a.npix_tiles = cdiv(a.M, BPIX);
@@ -616,7 +792,23 @@ static int launch_fast(GatherArgs& a, int groups, hipStream_t st) {
   dim3 grid(a.npix_tiles * a.nco_tiles, groups);
   static const int no_dma = getenv("S2P_NO_LDS_DMA") ? 1 : 0;
   static const int diag = getenv("S2P_DIAG") ? atoi(getenv("S2P_DIAG")) : 0;
-  a.diag = diag;      // A/B switch: register-staged fast kernel
+  a.diag = diag;
+  static const int no_halo = getenv("S2P_NO_HALO") ? 1 : 0;        // A/B switch: plain LDS-DMA kernel
+  if constexpr (BCO == 128 && BPIX == 128) {
+    if (!no_dma && !no_halo && a.istride == 1 && a.ostride == 1 && a.Qh == a.Hi && a.Qw == a.Wi && a.Ho == a.Qh &&
+        a.Wo == a.Qw && a.T >= 4) {
+      int lo = 0, hi = 0;
+      for (int t = 0; t < a.T; ++t) {
+        int off = (int)(signed char)(a.tap[t] & 0xff) * a.Wi + (int)(signed char)((a.tap[t] >> 8) & 0xff);
+        if (-off > lo) lo = -off;
+        if (off > hi) hi = off;
+      }
+      a.halo_lo = lo; a.halo_hi = hi;
+      const int npos = BPIX + lo + hi;
+      if (npos <= 176) { hipLaunchKernelGGL((conv_halo_kernel<176, true>), grid, dim3(256), 0, st, a); S2P_CHECK_LAUNCH("conv_halo_kernel"); return 0; }
+      if (npos <= 320) { hipLaunchKernelGGL((conv_halo_kernel<320, false>), grid, dim3(256), 0, st, a); S2P_CHECK_LAUNCH("conv_halo_kernel"); return 0; }
+    }
+  }
   if (no_dma) hipLaunchKernelGGL((conv_fast_kernel<BCO, BPIX, WCO, WPIX>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((conv_dma_kernel<BCO, BPIX, WCO, WPIX>), grid, dim3(256), 0, st, a);
   S2P_CHECK_LAUNCH("conv_fast_kernel");

@@ -55,6 +55,8 @@ CONV_CASES = [
     (64, 128, 4, 1, 2, False, False, 6, 6, 2),     # PatchGAN stride-1 layer
     (128, 1, 4, 1, 2, False, False, 7, 7, 2),      # PatchGAN head
     (40, 72, 1, 1, 0, False, False, 1, 1, 64),     # linear layer as 1x1 conv (non power-of-two channels)
+    (128, 192, 3, 1, 1, False, False, 21, 21, 3),  # halo-resident fast path: 2 channel slabs, tiles spanning rows and images
+    (64, 160, 5, 1, 2, False, False, 17, 23, 2),   # halo-resident path, 5x5 taps, ragged Cout tile
     (64, 3, 7, 1, 3, False, True, 40, 36, 2),      # out conv at a size that takes the spatially tiled MFMA path (ragged tiles)
     (32, 2, 5, 1, 2, False, False, 33, 37, 1),     # tiled path, zero padding, Cout=2, K=5
 ]
