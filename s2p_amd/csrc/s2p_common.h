@@ -89,3 +89,4 @@ bool s2p_thin_applicable(const s2p_conv_desc* d);
 int s2p_thin_fwd(const s2p_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int act, float slope,
                  hipStream_t st);
 int s2p_thin_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, int cin_real, hipStream_t st);
+

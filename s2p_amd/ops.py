@@ -14,6 +14,28 @@ from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, EPI_ADD, EPI_MUL_ACT
 
 IN_EPS = 1e-5
 
+# Zero arena: the reductions (IN moments, backward sums) accumulate with atomics into zero-initialised fp32 buffers.
+# Instead of ~90 tiny memsets per step, each network pass zeroes ONE slab and hands out views of it.
+_ARENA = None
+
+
+def arena_begin(device, nfloats=1 << 21):
+    global _ARENA
+    _ARENA = [torch.zeros(nfloats, dtype=torch.float32, device=device), 0]
+
+
+def zeros_f32(shape, device):
+    global _ARENA
+    n = 1
+    for d in shape:
+        n *= d
+    if _ARENA is not None and _ARENA[0].device == device and _ARENA[1] + n <= _ARENA[0].numel():
+        off = _ARENA[1]
+        _ARENA[1] = off + ((n + 3) // 4) * 4
+        return _ARENA[0][off:off + n].view(shape)
+    return torch.zeros(shape, dtype=torch.float32, device=device)
+
+
 # Optional in-situ profiler used by bench.py's roofline leg: when PROFILE is a list, every MFMA conv launch is
 # bracketed by two events on the launch stream and logged with its algorithmic FLOPs (2*MACs, un-padded channels).
 PROFILE = None
@@ -135,7 +157,7 @@ def channel_sum(dy, C, db):
 
 def in_stats(x, C):
     N, H, W, xp = x.shape
-    stats = torch.zeros((N, C, 2), dtype=torch.float32, device=x.device)
+    stats = zeros_f32((N, C, 2), x.device)
     check(lib().s2p_in_stats(dtype_id(x.dtype), ptr(x), N, H * W, C, xp, IN_EPS, ptr(stats), stream()), "s2p_in_stats")
     return stats
 
@@ -162,7 +184,7 @@ def in_bwd(da, x, C, stats, gb=None, gb_off=0, gb_st=None, st_off=0, act=ACT_NON
     """Backward of in_apply_fwd.  Returns (dx, sums[N,C,4]); writes d(gamma_img|beta_img) into dgb at dgb_off.
     sums[...,2] / sums[...,3] are d(gamma_st) / d(beta_st)."""
     N, H, W, xp = x.shape
-    sums = torch.zeros((N, C, 4), dtype=torch.float32, device=x.device)
+    sums = zeros_f32((N, C, 4), x.device)
     gbp, gb_pitch, stp, st_pitch = _gb_args(gb, gb_off, gb_st, st_off)
     dt = dtype_id(x.dtype)
     check(lib().s2p_in_bwd_reduce(dt, ptr(da), da.shape[3], ptr(x), N, H * W, C, xp, ptr(stats), gbp, gb_pitch, stp,
