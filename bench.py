@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--backend", type=str, default="", help="torch.distributed backend (default nccl = RCCL; gloo for a 1-GPU rehearsal)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use GPU 0")
     return ap.parse_args()
 
 
@@ -111,7 +113,14 @@ def main():
                   file=sys.stderr)
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a HIP device: the S2P hot path has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
+        os.environ["LOCAL_RANK"] = "0"
     torch.cuda.set_device(local_rank)
+    if world > 1 and args.backend:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=args.backend)
 
     from s2p_amd import ops
     from s2p_amd.options.train_options import TrainOptions
@@ -205,11 +214,13 @@ def main():
 
     # ---- roofline leg: one instrumented eager step, events around every MFMA conv launch --------------------
     roofline = None
-    if not args.no_roofline and rank == 0:
+    if not args.no_roofline:
+        # every rank runs the instrumented step (it contains the gradient all-reduces); rank 0 reports
         ops.PROFILE = []
         eager_step()
         torch.cuda.synchronize()
         recs, ops.PROFILE = ops.PROFILE, None
+    if not args.no_roofline and rank == 0:
         print("[bench] roofline leg done (%d conv launches)" % len(recs), file=sys.stderr, flush=True)
         tot_f = sum(r["flops"] for r in recs)
         tot_ms = sum(r["events"][0].elapsed_time(r["events"][1]) for r in recs)
@@ -219,7 +230,17 @@ def main():
             k[0] += r["flops"]; k[1] += r["events"][0].elapsed_time(r["events"][1]); k[2] += 1
         # dominant kernel: the implicit-GEMM conv family (conv_gather_kernel + wgrad_kernel), all launches of one step
         ach = tot_f / (tot_ms * 1e-3) / 1e12
-        roofline = dict(bound="mfma", kernel="conv_gather_kernel<bf16>/wgrad_kernel<bf16> (all %d launches of one step)" % len(recs),
+        groups = {}
+        for r in recs:
+            gk = groups.setdefault((r["kind"], r["shape"]), [0.0, 0.0, 0])
+            gk[0] += r["flops"]; gk[1] += r["events"][0].elapsed_time(r["events"][1]); gk[2] += 1
+        (dk, dshape), dv = max(groups.items(), key=lambda kv: kv[1][1])
+        dominant = dict(kind=dk, shape_N_H_W_Cin_Cout_k_stride_groups_transposed=list(dshape), launches_per_step=dv[2],
+                        avg_launch_us=round(dv[1] * 1e3 / dv[2], 2), gflop_per_launch=round(dv[0] / dv[2] / 1e9, 2),
+                        tflops=round(dv[0] / (dv[1] * 1e-3) / 1e12, 2), frac=round(dv[0] / (dv[1] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4))
+        roofline = dict(bound="mfma", kernel="implicit-GEMM conv family: conv_halo/conv_dma/conv_gather (fwd, dgrad) + wgrad_dma/wgrad "
+                                             "+ thin_tiled kernels, all %d launches of one step" % len(recs),
+                        dominant_layer=dominant,
                         achieved=round(ach, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                         traffic=None, algorithmic_gflop_per_step=round(tot_f / 1e9, 1), conv_ms_per_step=round(tot_ms, 3),
                         avg_launch_us=round(tot_ms * 1e3 / max(len(recs), 1), 2),
@@ -227,7 +248,7 @@ def main():
                                          tflops=round(v[0] / (v[1] * 1e-3) / 1e12, 2)) for k, v in by_kind.items()})
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, opt.state_dim)
 
     if rank == 0:

@@ -182,3 +182,46 @@ def test_trainer_steps_and_checkpoint(hip_device, tmp_path):
     for k, shp in O.generator_param_shapes(O.Spec()).items():
         assert tuple(ck["netG"][k].shape) == tuple(shp) and ck["netG"][k].is_contiguous()
     assert torch.equal(ck["netG"]["out.weight"], w1)
+
+
+def test_rollout_matches_oracle_and_golden(hip_device, tmp_path):
+    """N-step autoregressive generation (config 1/5 path): frames stay on the device in NHWC between steps."""
+    import numpy as np
+    from s2p_amd.options.test_options import TestOptions
+    from s2p_amd.rollout import rollout
+    sys_path_golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    import sys
+    sys.path.insert(0, sys_path_golden)
+    from make_golden import golden_inputs, golden_params
+    G = np.load(os.path.join(sys_path_golden, "s2p_golden_v1.npz"))
+    opt = TestOptions().parse(["--env_type", "cheetah", "--gpu_ids", "0", "--random_init", "--precision", "fp32",
+                               "--checkpoints_dir", str(tmp_path)], quiet=True)
+    model = Pix2PixModel(opt)
+    spec = O.Spec()
+    pg, _, _ = golden_params(spec)
+    model.netG.load_state_dict(pg)
+    prev, state, _ = golden_inputs()
+    states = torch.stack([state, state * 0.5, -state], 1)
+    frames = rollout(model.netG, prev, states).cpu()
+    assert frames.shape == (1, 3, 3, 84, 84)
+    assert rel(frames[:, 0], torch.from_numpy(G["fake"])) < 1e-3            # committed golden vector
+    assert rel(frames[:, -1], torch.from_numpy(G["rollout_last"])) < 1e-3
+    ref = O.rollout(pg, prev, states, spec)
+    assert rel(frames, ref) < 1e-3
+
+
+def test_generator_256x256_bf16_runs_and_matches(hip_device, tmp_path):
+    """Config-5 shape: the same fully-convolutional generator at 256x256 (batch 2 here)."""
+    from s2p_amd.options.test_options import TestOptions
+    opt = TestOptions().parse(["--env_type", "cheetah", "--gpu_ids", "0", "--random_init", "--precision", "bf16",
+                               "--checkpoints_dir", str(tmp_path), "--crop_size", "256"], quiet=True)
+    model = Pix2PixModel(opt)
+    spec = O.Spec()
+    pg = randomize(O.init_params(O.generator_param_shapes(spec), 1), 11, 1.0)
+    model.netG.load_state_dict(pg)
+    prev, state, _ = make_inputs(2, 256, 256, 17, seed=9)
+    with torch.no_grad():
+        y = model.netG(prev.cuda(), state.cuda()).cpu()
+        y_ref = O.generator_forward(pg, prev, state, spec)
+    assert y.shape == (2, 3, 256, 256)
+    assert rel(y, y_ref) < 6e-2
