@@ -84,6 +84,31 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// ---- hand-issued LDS-DMA (buffer_load_dwordx4 ... lds) ---------------------------------------------------------
+// Issued from inline asm so that hipcc does not see the LDS write: with the builtin, hipcc inserts `s_waitcnt vmcnt(0)`
+// before the next LDS read of the staged array, which serialises a multi-stage pipeline.  The caller counts the
+// DMAs it has in flight and places `s_waitcnt vmcnt(N)` + `s_barrier` itself (cdna_hip_programming.md 5.7).
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+__device__ __forceinline__ i32x4 s2p_make_rsrc(const void* p, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)p;
+  i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffull));
+  r[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffull));      // stride 0
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ unsigned s2p_lds_addr(const void* p) {
+  return (unsigned)(unsigned long long)((__attribute__((address_space(3))) const char*)p);
+}
+// lds_dst: wave-uniform LDS byte address of this wave's 1-KiB piece; voffset: this lane's byte offset into the buffer
+// (an offset >= the descriptor's size returns zeros).  M0 is written in the same statement that consumes it.
+__device__ __forceinline__ void s2p_dma16(i32x4 rsrc, unsigned lds_dst, int voffset) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+               :: "v"(voffset), "s"(rsrc), "s"(lds_dst) : "memory");
+}
+#define S2P_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
 // thin-Cout direct convolutions (thin_conv.hip)
 bool s2p_thin_applicable(const s2p_conv_desc* d);
 int s2p_thin_fwd(const s2p_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int act, float slope,

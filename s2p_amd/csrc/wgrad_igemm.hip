@@ -207,7 +207,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
   constexpr int BT = 128, RS = 256, TT = 2;
   constexpr int NP = BKP / 16;                        // DMA pieces (4 rows) per wave per operand per step
   constexpr int TILE = BKP * RS;                      // 8 KiB per operand
-  __shared__ __attribute__((aligned(1024))) char smem[4 * TILE];
+  constexpr int NST = 3;                              // pipeline stages: two K steps of LDS-DMA in flight behind the MFMAs
+  __shared__ __attribute__((aligned(1024))) char smem[NST * 2 * TILE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // XCD-aware mapping: workgroups b, b+8, ... share an XCD (and its 4 MiB L2).  All tiles of one (group, split)
@@ -241,8 +242,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
   const int tdy = (int)(signed char)(ti & 0xff), tdx = (int)(signed char)((ti >> 8) & 0xff);
   const T* Ag = (const T*)a.A + (size_t)g * a.a_gstride;
   const T* Bg = (const T*)a.B + (size_t)g * a.b_gstride;
-  __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)Ag, 0, a.a_bytes - (unsigned)g * (unsigned)a.a_gstride * 2u, 0x00020000);
-  __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc((void*)Bg, 0, a.b_bytes - (unsigned)g * (unsigned)a.b_gstride * 2u, 0x00020000);
+  const i32x4 ar = s2p_make_rsrc(Ag, a.a_bytes - (unsigned)g * (unsigned)a.a_gstride * 2u);
+  const i32x4 br = s2p_make_rsrc(Bg, a.b_bytes - (unsigned)g * (unsigned)a.b_gstride * 2u);
 
   const int step0 = split * a.steps_per_split;
   int nsteps = a.steps_per_split;
@@ -260,9 +261,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
     int n = m / QQ, rr = m - n * QQ, qy = rr / a.Qw, qx = rr - qy * a.Qw;
     pn[i] = n; py[i] = qy; px[i] = qx;
   }
-  typedef __attribute__((address_space(3))) void* lds_ptr;
   auto issue = [&](int buf) {
-    char* base = smem + buf * 2 * TILE + wave * (4 * RS);
+    const unsigned base = s2p_lds_addr(smem) + buf * 2 * TILE + wave * (4 * RS);
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const bool mok = pm[i] < a.M;
@@ -274,8 +274,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
       }
       const bool bok = mok && b_ok && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi;
       unsigned bo = bok ? (unsigned)((((pn[i] * a.Hi + iy) * a.Wi + ix) * a.b_pitch + bc) * 2) : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ar, (lds_ptr)(base + i * (16 * RS)), 16, (int)ao, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(br, (lds_ptr)(base + TILE + i * (16 * RS)), 16, (int)bo, 0, 0, 0);
+      s2p_dma16(ar, base + i * (16 * RS), (int)ao);
+      s2p_dma16(br, base + TILE + i * (16 * RS), (int)bo);
       pm[i] += BKP; px[i] += BKP;
       while (px[i] >= a.Qw) { px[i] -= a.Qw; if (++py[i] >= a.Qh) { py[i] = 0; ++pn[i]; } }
     }
@@ -301,11 +301,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
   // transposed-read lane geometry (see wgrad_kernel): group gq = lane>>4 -> channel block 16*(gq&1), k half gq>>1
   const int gq = lane >> 4, gg = gq & 1, hh = gq >> 1, q = (lane >> 2) & 3, p = lane & 3;
 
+  // 3-stage pipeline: while step kt computes, the DMAs of steps kt+1 and kt+2 are in flight.  The only waits are a
+  // counted vmcnt (all but the newest stage's 2*NP DMA instructions) and a raw s_barrier -- never vmcnt(0) in the loop.
   issue(0);
-  __syncthreads();
+  if (nsteps > 1) issue(1);
+  if (nsteps > 1) S2P_WAIT_VMCNT(2 * NP);
+  else S2P_WAIT_VMCNT(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  int stage = 0;
   for (int kt = 0; kt < nsteps; ++kt) {
-    if (kt + 1 < nsteps && a.diag != 1) issue((kt + 1) & 1);
-    const char* At = smem + (kt & 1) * 2 * TILE;
+    int st2 = stage + 2; if (st2 >= NST) st2 -= NST;
+    if (kt + 2 < nsteps && a.diag != 1) issue(st2);
+    const char* At = smem + stage * 2 * TILE;
     const char* Bt = At + TILE;
     if (a.diag != 2)
 #pragma unroll
@@ -346,7 +354,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
         for (int i = 0; i < TT; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], ones, accb[i], 0, 0, 0);
       }
     }
-    __syncthreads();
+    // stage kt+1 must have landed (for every wave) before anyone reads it; stage kt+2 may stay in flight
+    if (kt + 2 < nsteps) S2P_WAIT_VMCNT(2 * NP);
+    else S2P_WAIT_VMCNT(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);                 // no LDS read may be scheduled above the wait + barrier
+    if (++stage == NST) stage = 0;
   }
 
   const int r = lane & 31, h = lane >> 5;
