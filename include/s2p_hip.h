@@ -136,6 +136,11 @@ int s2p_nchw_to_nhwc(int dtype, const float* x, int N, int C, int H, int W, void
                      int c_off, int zero_pad, void* stream);
 int s2p_nhwc_to_nchw(int dtype, const void* x, int x_pitch, int c_off, int N, int C, int H, int W,
                      float* y, int accumulate, void* stream);
+/* dataset frames: uint8 NHWC [pixels][C] (the layout rlkit/torch/slac/algo.py:189-190 reads) ->
+ * NHWC dtype in [-1,1] with zero-padded pitch (v = u8/127.5 - 1), and back
+ * (u8 = clamp(round((v+1)*127.5))); the round trip is exact on all 256 values.          */
+int s2p_u8_to_nhwc(int dtype, const void* x, int64_t pixels, int C, void* y, int y_pitch, void* stream);
+int s2p_nhwc_to_u8(int dtype, const void* x, int x_pitch, int64_t pixels, int C, void* y, void* stream);
 /* generic cast copy between dtypes (n elements)                                         */
 int s2p_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, void* stream);
 

@@ -59,6 +59,8 @@ SIGNATURES = {
     "s2p_nchw_to_nhwc": [c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P],
     "s2p_nhwc_to_nchw": [c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P],
     "s2p_cast": [c_int, _P, c_int, _P, c_int64, _P],
+    "s2p_u8_to_nhwc": [c_int, _P, c_int64, c_int, _P, c_int, _P],
+    "s2p_nhwc_to_u8": [c_int, _P, c_int, c_int64, c_int, _P, _P],
     "s2p_l1_loss": [c_int, _P, _P, c_int64, c_float, _P, _P, c_int, _P],
     "s2p_hinge_loss": [c_int, _P, c_int64, c_int, c_float, _P, _P, _P],
     "s2p_adam_step": [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int, c_float, _P],

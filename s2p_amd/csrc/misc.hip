@@ -493,3 +493,46 @@ extern "C" int s2p_copy_channels(int dtype, const void* src, int src_pitch, int 
   S2P_CHECK_LAUNCH("copy_channels_kernel");
   return 0;
 }
+
+// ---- dataset image formats (bulk augmentation caller) --------------------------------
+// uint8 NHWC [P][C] frames (rlkit/torch/slac/algo.py:189-190 reads them NHWC) <-> NHWC compute dtype in [-1,1].
+//   in : v = u8 / 127.5 - 1      (zero-padded to `pitch` channels)
+//   out: u8 = clamp(round((v + 1) * 127.5), 0, 255)   -- exact inverse on the 256 representable values
+template <typename T>
+__global__ void u8_to_nhwc_kernel(const unsigned char* x, long long pixels, int C, T* y, int pitch) {
+  long long total = pixels * pitch;
+  GRID_STRIDE(idx, total) {
+    long long p = idx / pitch; int c = (int)(idx - p * pitch);
+    float v = c < C ? (float)x[p * C + c] / 127.5f - 1.f : 0.f;      // true division: 255 -> exactly 1.0
+    y[idx] = from_f32<T>(v);
+  }
+}
+template <typename T>
+__global__ void nhwc_to_u8_kernel(const T* x, int pitch, long long pixels, int C, unsigned char* y) {
+  long long total = pixels * C;
+  GRID_STRIDE(idx, total) {
+    long long p = idx / C; int c = (int)(idx - p * C);
+    float v = (to_f32(x[p * pitch + c]) + 1.f) * 127.5f;
+    v = rintf(v);
+    v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
+    y[idx] = (unsigned char)v;
+  }
+}
+extern "C" int s2p_u8_to_nhwc(int dtype, const void* x, int64_t pixels, int C, void* y, int y_pitch, void* stream) {
+  if (!x || !y || C > y_pitch) S2P_FAIL(-1, "s2p_u8_to_nhwc: bad argument");
+  long long total = (long long)pixels * y_pitch;
+  if (dtype == S2P_F32) hipLaunchKernelGGL(u8_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)x, (long long)pixels, C, (float*)y, y_pitch);
+  else if (dtype == S2P_BF16) hipLaunchKernelGGL(u8_to_nhwc_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)x, (long long)pixels, C, (__bf16*)y, y_pitch);
+  else S2P_FAIL(-1, "s2p_u8_to_nhwc: bad dtype");
+  S2P_CHECK_LAUNCH("u8_to_nhwc_kernel");
+  return 0;
+}
+extern "C" int s2p_nhwc_to_u8(int dtype, const void* x, int x_pitch, int64_t pixels, int C, void* y, void* stream) {
+  if (!x || !y || C > x_pitch) S2P_FAIL(-1, "s2p_nhwc_to_u8: bad argument");
+  long long total = (long long)pixels * C;
+  if (dtype == S2P_F32) hipLaunchKernelGGL(nhwc_to_u8_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_pitch, (long long)pixels, C, (unsigned char*)y);
+  else if (dtype == S2P_BF16) hipLaunchKernelGGL(nhwc_to_u8_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, x_pitch, (long long)pixels, C, (unsigned char*)y);
+  else S2P_FAIL(-1, "s2p_nhwc_to_u8: bad dtype");
+  S2P_CHECK_LAUNCH("nhwc_to_u8_kernel");
+  return 0;
+}

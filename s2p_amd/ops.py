@@ -320,3 +320,19 @@ def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, step_dev, grad_scale=1.0):
     """Graph-capturable Adam: `step_dev` is an int32 device tensor incremented on the device."""
     check(lib().s2p_adam_step_dev(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, ptr(step_dev),
                                   grad_scale, stream()), "s2p_adam_step_dev")
+
+
+def u8_to_nhwc(x_u8, dtype, pitch):
+    """uint8 NHWC frames [N,H,W,C] on the device -> compute-dtype NHWC in [-1,1], zero-padded to `pitch` channels."""
+    N, H, W, C = x_u8.shape
+    y = torch.empty((N, H, W, pitch), dtype=dtype, device=x_u8.device)
+    check(lib().s2p_u8_to_nhwc(dtype_id(dtype), ptr(x_u8), N * H * W, C, ptr(y), pitch, stream()), "s2p_u8_to_nhwc")
+    return y
+
+
+def nhwc_to_u8(x, C, out=None):
+    """compute-dtype NHWC in [-1,1] -> uint8 NHWC [N,H,W,C] (the on-disk layout of image_observations*)."""
+    N, H, W, xp = x.shape
+    y = out if out is not None else torch.empty((N, H, W, C), dtype=torch.uint8, device=x.device)
+    check(lib().s2p_nhwc_to_u8(dtype_id(x.dtype), ptr(x), xp, N * H * W, C, ptr(y), stream()), "s2p_nhwc_to_u8")
+    return y
