@@ -30,7 +30,7 @@ extern "C" {
 #define S2P_VERSION 100
 
 enum { S2P_F32 = 0, S2P_BF16 = 1 };
-enum { S2P_ACT_NONE = 0, S2P_ACT_RELU = 1, S2P_ACT_LRELU = 2, S2P_ACT_TANH = 3 };
+enum { S2P_ACT_NONE = 0, S2P_ACT_RELU = 1, S2P_ACT_LRELU = 2, S2P_ACT_TANH = 3, S2P_ACT_SWISH = 4 };
 /* epilogue modes of the conv family */
 enum { S2P_EPI_STORE = 0,       /* y = act(conv + bias)                                   */
        S2P_EPI_ADD = 1,         /* y = act(conv + bias) + aux          (residual add)     */
@@ -155,6 +155,21 @@ int s2p_l1_loss(int dtype, const void* a, const void* b, int64_t count, float sc
  *   mode 2: loss += -scale*sum(x),       grad = -scale              (G)                */
 int s2p_hinge_loss(int dtype, const void* x, int64_t count, int mode, float scale,
                    float* loss_out, void* grad_x, void* stream);
+
+/* ---- ensemble state-dynamics head (reference gaussian_ensemble.py:83-96 and
+ *      state_transition_rollout.py:192-204) ------------------------------------------------
+ * raw   : fp32 [B][E*2*D] output of the last ensemble layer (member e at columns e*2D: mu | logstd)
+ * xin   : fp32 [B][x_pitch] normalised (obs, action); obs_dim = D-1 leading columns
+ * mean/std: fp32 [E][B][D] (may be NULL): mu (obs part + input obs, 'local' mode) and
+ *         exp(soft_clamp(logstd, min_logstd, max_logstd))
+ * pick  : int32 [B] member index per sample; next_obs [B][D-1] = mean[pick]*obs_std+obs_mean,
+ *         reward [B] = mean[pick][D-1]*rew_std+rew_mean
+ * disagreement[B] = max_e || mean_e[:D-1] - avg_e mean[:D-1] ||_2 ; aleatoric[B] = max_e || std_e ||_2 */
+int s2p_ensemble_head(const float* raw, int raw_pitch, const float* xin, int x_pitch, int B, int E, int D,
+                      const float* min_logstd, const float* max_logstd, float* mean, float* std,
+                      const int32_t* pick, const float* obs_mean, const float* obs_std, float rew_mean,
+                      float rew_std, float* next_obs, float* reward, float* disagreement, float* aleatoric,
+                      void* stream);
 
 /* ---- optimizer + weight packing ---------------------------------------------------- */
 /* torch.optim.Adam step on flat fp32 buffers; g is multiplied by grad_scale first.      */

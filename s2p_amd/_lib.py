@@ -10,10 +10,10 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "csrc", "libs2p_hip.so")
+_SO = os.environ.get("S2P_LIB") or os.path.join(_HERE, "csrc", "libs2p_hip.so")     # S2P_LIB: A/B a second build
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SWISH = 0, 1, 2, 3, 4
 EPI_STORE, EPI_ADD, EPI_MUL_ACTGRAD = 0, 1, 2
 
 c_int, c_float, c_void_p, c_int64 = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64
@@ -64,6 +64,8 @@ SIGNATURES = {
     "s2p_l1_loss": [c_int, _P, _P, c_int64, c_float, _P, _P, c_int, _P],
     "s2p_hinge_loss": [c_int, _P, c_int64, c_int, c_float, _P, _P, _P],
     "s2p_adam_step": [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int, c_float, _P],
+    "s2p_ensemble_head": [_P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, _P,
+                          _P, _P, _P],
     "s2p_adam_step_dev": [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, _P, c_float, _P],
     "s2p_pack_weights": [_P, c_int, c_int, _P],
     "s2p_act_bwd": [c_int, _P, _P, c_int64, c_int, c_float, _P, _P],

@@ -743,8 +743,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
     const int c0 = slab * BK;
     int ntap = tap + 1, nslab_i = slab;
     if (ntap == a.T) { ntap = 0; ++nslab_i; }
-    if (kt + 1 < nk) issue_w((kt + 1) & 1, ntap, nslab_i * BK);
-    if (DBUF && tap == 0 && slab + 1 < nslab) issue_halo((slab + 1) & 1, c0 + BK);
+    if (kt + 1 < nk && a.diag != 1) issue_w((kt + 1) & 1, ntap, nslab_i * BK);
+    if (DBUF && tap == 0 && slab + 1 < nslab && a.diag != 1) issue_halo((slab + 1) & 1, c0 + BK);
     const char* hb = hbase + (DBUF ? (slab & 1) * HALO : 0);
     const int ti = a.tap[tap];
     const int toff = (int)(signed char)(ti & 0xff) * a.Wi + (int)(signed char)((ti >> 8) & 0xff);
@@ -758,6 +758,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
       prow[j] = ok ? hb + hp * RS : zrow;
       psw[j] = ok ? (hp >> 1) & 7 : 0;
     }
+    if (a.diag != 2)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       bf16x8 af[TCO], bf[TPIX];

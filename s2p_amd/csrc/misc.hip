@@ -536,3 +536,61 @@ extern "C" int s2p_nhwc_to_u8(int dtype, const void* x, int x_pitch, int64_t pix
   S2P_CHECK_LAUNCH("nhwc_to_u8_kernel");
   return 0;
 }
+
+// ---- ensemble dynamics head (N2) ------------------------------------------------------------------------------
+// one thread per sample: E*2D raw values -> soft-clamped std, local-mode mean, member pick + de-normalisation and the
+// two uncertainty reductions of state_transition_rollout.py:199-204.  E*D <= 7*32 values are kept in registers/local.
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }   // F.softplus (threshold 20)
+__global__ void ensemble_head_kernel(const float* raw, int rp, const float* xin, int xp, int B, int E, int D,
+                                     const float* mn, const float* mx, float* mean, float* sd, const int* pick,
+                                     const float* om, const float* os, float rm, float rs, float* nobs, float* rew,
+                                     float* dis, float* ale) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int Do = D - 1;
+  float avg[32];
+  for (int d = 0; d < Do; ++d) avg[d] = 0.f;
+  float amax = 0.f;
+  const int pk = pick ? pick[b] : 0;
+  for (int e = 0; e < E; ++e) {
+    const float* r = raw + (size_t)b * rp + e * 2 * D;
+    float s2 = 0.f;
+    for (int d = 0; d < D; ++d) {
+      float mu = r[d] + (d < Do ? xin[(size_t)b * xp + d] : 0.f);          // 'local' mode: obs part is a delta
+      float ls = r[D + d];
+      ls = mx[d] - softplus_f(mx[d] - ls);                                   // soft_clamp upper, then lower
+      ls = mn[d] + softplus_f(ls - mn[d]);
+      float s = expf(ls);
+      s2 += s * s;
+      if (d < Do) avg[d] += mu;
+      if (mean) mean[((size_t)e * B + b) * D + d] = mu;
+      if (sd) sd[((size_t)e * B + b) * D + d] = s;
+      if (pick && e == pk) { if (d < Do) nobs[(size_t)b * Do + d] = mu * os[d] + om[d]; else rew[b] = mu * rs + rm; }
+    }
+    amax = fmaxf(amax, sqrtf(s2));
+  }
+  if (ale) ale[b] = amax;
+  if (dis) {
+    float dmax = 0.f;
+    for (int e = 0; e < E; ++e) {
+      const float* r = raw + (size_t)b * rp + e * 2 * D;
+      float s2 = 0.f;
+      for (int d = 0; d < Do; ++d) { float df = r[d] + xin[(size_t)b * xp + d] - avg[d] / (float)E; s2 += df * df; }
+      dmax = fmaxf(dmax, sqrtf(s2));
+    }
+    dis[b] = dmax;
+  }
+}
+extern "C" int s2p_ensemble_head(const float* raw, int raw_pitch, const float* xin, int x_pitch, int B, int E, int D,
+                                 const float* min_logstd, const float* max_logstd, float* mean, float* std,
+                                 const int32_t* pick, const float* obs_mean, const float* obs_std, float rew_mean,
+                                 float rew_std, float* next_obs, float* reward, float* disagreement, float* aleatoric,
+                                 void* stream) {
+  if (!raw || !xin || !min_logstd || !max_logstd || D < 2 || D > 33 || E < 1) S2P_FAIL(-1, "s2p_ensemble_head: bad argument");
+  if (pick && (!obs_mean || !obs_std || !next_obs || !reward)) S2P_FAIL(-1, "s2p_ensemble_head: pick needs outputs");
+  hipLaunchKernelGGL(ensemble_head_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream, raw, raw_pitch, xin, x_pitch,
+                     B, E, D, min_logstd, max_logstd, mean, std, (const int*)pick, obs_mean, obs_std, rew_mean, rew_std,
+                     next_obs, reward, disagreement, aleatoric);
+  S2P_CHECK_LAUNCH("ensemble_head_kernel");
+  return 0;
+}

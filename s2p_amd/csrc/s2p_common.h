@@ -63,6 +63,7 @@ __device__ __forceinline__ float act_fwd(float v, int act, float slope) {
     case S2P_ACT_RELU: return v > 0.f ? v : 0.f;
     case S2P_ACT_LRELU: return v > 0.f ? v : v * slope;
     case S2P_ACT_TANH: return tanhf(v);
+    case S2P_ACT_SWISH: return v / (1.f + expf(-v));        // x * sigmoid(x)  (gaussian_ensemble.py:9-11)
     default: return v;
   }
 }
