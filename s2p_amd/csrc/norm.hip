@@ -6,6 +6,7 @@
 //                                       producer epilogue accumulate the moments instead of a stats pass)
 //   y  = act( xhat * (1 + g_img + g_st) + (b_img + b_st) ),   xhat = (x - mean) * rstd
 #include "s2p_common.h"
+#include <stdlib.h>
 
 struct NormArgs {
   const void* x; const void* da; const void* gb; const float* gbst; const float* stats; float* sums;
@@ -223,7 +224,8 @@ static int launch_reduce(int dtype, NormArgs& a, hipStream_t st) {
 template <int MODE>
 static int launch_apply(int dtype, NormArgs& a, hipStream_t st) {
   int slabs = cdiv(a.C, 64);
-  int ps = cdiv(2048, slabs * a.N);                     // aim at >= 2048 workgroups (8 per CU)
+  static const int target = getenv("S2P_NORM_BLOCKS") ? atoi(getenv("S2P_NORM_BLOCKS")) : 1024;
+  int ps = cdiv(target, slabs * a.N);                   // aim at >= `target` workgroups
   int maxps = cdiv(a.HW, 64); if (ps > maxps) ps = maxps; if (ps < 1) ps = 1;
   a.psplit = ps; a.rows_per_split = cdiv(a.HW, ps);
   dim3 grid(slabs, a.N, cdiv(a.HW, a.rows_per_split));

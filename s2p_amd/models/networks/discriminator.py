@@ -135,15 +135,34 @@ class MultiscaleDiscriminator(BaseNetwork):
             d.compute_dtype = dt
             d.finalized = True
 
+    def _side_stream(self):
+        s = getattr(self, "_side", None)
+        if s is None:
+            s = self._side = torch.cuda.Stream()
+        return s
+
     def fwd_nhwc(self, x):
+        """The scales are independent given their inputs; the coarser scales' kernels are too small to fill 256 CUs, so
+        scales >= 1 run on a side stream, overlapped with scale 0 (fork/join captured by hipGraph)."""
         self._require_ready()
-        result, ctx = [], []
-        for i, d in enumerate(self.subnets()):
-            feats, saved = d.fwd_nhwc(x)
-            result.append(feats)
-            ctx.append((x, saved))
-            if i + 1 < self.num_D:
-                x = ops.avgpool_fwd(x)
+        main = torch.cuda.current_stream()
+        side = self._side_stream()
+        subs = self.subnets()
+        xs = [x]
+        for i in range(1, self.num_D):
+            xs.append(ops.avgpool_fwd(xs[-1]))
+        result, ctx = [None] * self.num_D, [None] * self.num_D
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for i in range(1, self.num_D):
+                xs[i].record_stream(side)
+                feats, saved = subs[i].fwd_nhwc(xs[i])
+                for f in feats:
+                    f.record_stream(main)
+                result[i], ctx[i] = feats, (xs[i], saved)
+        feats, saved = subs[0].fwd_nhwc(xs[0])
+        result[0], ctx[0] = feats, (xs[0], saved)
+        main.wait_stream(side)
         return result, ctx
 
     def bwd_nhwc(self, ctx, grads, need_wgrad=True, need_dx=True, n_keep=None):

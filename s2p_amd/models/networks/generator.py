@@ -172,14 +172,21 @@ class S2PGenerator(BaseNetwork):
         if H % (1 << self.n_down) or W % (1 << self.n_down):
             raise ValueError(f"image size {H}x{W} must be a multiple of {1 << self.n_down}")
         ctx = {}
-        # state path
-        pe_pitch = pad_to(self.state_dim * (1 + 2 * self.L_oct), 4)
-        h = ops.posenc(state.contiguous(), self.L_oct, pe_pitch).view(N, 1, 1, pe_pitch)
-        hs = [h]
-        for i in range(self.n_mlp):
-            h = L[f"fc{i}"].fwd(h, act=ACT_LRELU, slope=LRELU)
-            hs.append(h)
-        st_all = L["fc_state"].fwd(h).view(N, -1)                       # [N, 12*2C] fp32
+        # state path: a chain of tiny fp32 GEMMs (2..48 workgroups each).  It is independent of the image-conditioning
+        # convs and the encoder, so it runs on a side stream and overlaps them (the fork/join is captured by hipGraph).
+        main = torch.cuda.current_stream()
+        side = self._side_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            pe_pitch = pad_to(self.state_dim * (1 + 2 * self.L_oct), 4)
+            h = ops.posenc(state.contiguous(), self.L_oct, pe_pitch).view(N, 1, 1, pe_pitch)
+            hs = [h]
+            for i in range(self.n_mlp):
+                h = L[f"fc{i}"].fwd(h, act=ACT_LRELU, slope=LRELU)
+                hs.append(h)
+            st_all = L["fc_state"].fwd(h).view(N, -1)                   # [N, 12*2C] fp32
+        st_all.record_stream(main)          # allocated on the side stream, consumed by the norms on the main stream
+        state.record_stream(side)
         # image conditioning
         hq, wq = H >> self.n_down, W >> self.n_down
         seg = ops.resize_nearest(img, hq, wq)
@@ -200,6 +207,7 @@ class S2PGenerator(BaseNetwork):
             a = ops.in_apply_fwd(x, c, s, act=ACT_RELU)
             enc.append((xin, x, s, a))
         # MAT residual blocks
+        main.wait_stream(side)                                          # st_all is needed from here on
         blocks = []
         x = a
         for b in range(self.n_blocks):
@@ -226,6 +234,12 @@ class S2PGenerator(BaseNetwork):
             ctx.update(hs=hs, st_all=st_all, seg=seg, actv=actv, gb_all=gb_all, enc=enc, blocks=blocks, dec=dec,
                        out=out, last=x)
         return out, ctx
+
+    def _side_stream(self):
+        s = getattr(self, "_side", None)
+        if s is None:
+            s = self._side = torch.cuda.Stream()
+        return s
 
     @property
     def L_oct(self):
@@ -267,16 +281,21 @@ class S2PGenerator(BaseNetwork):
         L["gb"].wgrad(actv, dgb_all)
         d_actv = L["gb"].dgrad(dgb_all, actv.shape, aux=actv, epi=EPI_MUL_ACTGRAD, aux_act=ACT_RELU)
         L["shared"].wgrad(seg, d_actv)
-        # state path
-        hs = ctx["hs"]
-        dstv = dst_all.view(N, 1, 1, -1)
-        L["fc_state"].wgrad(hs[-1], dstv)
-        dh = L["fc_state"].dgrad(dstv, hs[-1].shape)
-        for i in reversed(range(self.n_mlp)):
-            dpre = ops.act_bwd(dh, hs[i + 1], ACT_LRELU, LRELU)
-            L[f"fc{i}"].wgrad(hs[i], dpre)
-            if i > 0:
-                dh = L[f"fc{i}"].dgrad(dpre, hs[i].shape)
+        # state path backward on the side stream, overlapped with the encoder backward below
+        main = torch.cuda.current_stream()
+        side = self._side_stream()
+        side.wait_stream(main)
+        dst_all.record_stream(side)
+        with torch.cuda.stream(side):
+            hs = ctx["hs"]
+            dstv = dst_all.view(N, 1, 1, -1)
+            L["fc_state"].wgrad(hs[-1], dstv)
+            dh = L["fc_state"].dgrad(dstv, hs[-1].shape)
+            for i in reversed(range(self.n_mlp)):
+                dpre = ops.act_bwd(dh, hs[i + 1], ACT_LRELU, LRELU)
+                L[f"fc{i}"].wgrad(hs[i], dpre)
+                if i > 0:
+                    dh = L[f"fc{i}"].dgrad(dpre, hs[i].shape)
         # encoder
         for i in reversed(range(self.n_down)):
             xin, x, s, a = ctx["enc"][i + 1]
@@ -286,6 +305,7 @@ class S2PGenerator(BaseNetwork):
         img, x, s, a = ctx["enc"][0]
         dxe, _ = ops.in_bwd(dx, x, self.ngf, s, act=ACT_RELU)
         L["stem"].wgrad(img, dxe)
+        main.wait_stream(side)
 
     # ---- public torch-style API --------------------------------------------------------------------------------
     def forward(self, prev_image, state):
