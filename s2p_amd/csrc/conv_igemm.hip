@@ -45,25 +45,53 @@ __device__ __forceinline__ void conv_epilogue(const GatherArgs& a, f32x16 (&acc)
   constexpr int CE = DT<T>::CE;
   constexpr int ERS = BCO * (int)sizeof(T) + 16;
   // ---- epilogue: bias + activation in registers, transpose through LDS, 16-B stores ----------
+  // The activation / epilogue selectors are kernel arguments; they are resolved ONCE per wave here (uniform
+  // selects of a negative-side slope), never per element: a per-element switch costs ~6 us per launch in scalar
+  // branches and instruction fetch.  relu / lrelu / none all are  v > 0 ? v : v * ns  with ns = 0 / slope / 1.
   const float* bias = (a.bias && blockIdx.z == 0) ? a.bias + (size_t)g * a.Cout : nullptr;
+  const bool act_generic = (a.act == S2P_ACT_TANH || a.act == S2P_ACT_SWISH);
+  const float ns = a.act == S2P_ACT_RELU ? 0.f : (a.act == S2P_ACT_LRELU ? a.slope : 1.f);
+  if (bias) {
+#pragma unroll
+    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int co = co_base + wco0 + 32 * i + 8 * q4 + 4 * h;
+        float bv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = (co + e < a.Cout) ? bias[co + e] : 0.f;
+#pragma unroll
+        for (int j = 0; j < TPIX; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][4 * q4 + e] += bv[e];
+      }
+  }
+  if (act_generic) {
+#pragma unroll                                           // (static register indices: a rolled loop would spill acc)
+    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+      for (int j = 0; j < TPIX; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float t = acc[i][j][e];
+          acc[i][j][e] = a.act == S2P_ACT_TANH ? tanhf(t) : t / (1.f + expf(-t));
+        }
+  }
 #pragma unroll
   for (int i = 0; i < TCO; ++i) {
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
       int col = wco0 + 32 * i + 8 * q4 + 4 * h;     // local co of element e=0
-      float bv[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        int co = co_base + col + e;
-        bv[e] = (bias && co < a.Cout) ? bias[co] : 0.f;
-      }
 #pragma unroll
       for (int j = 0; j < TPIX; ++j) {
         int prow_l = wpix0 + 32 * j + r;
         char* dst = smem + prow_l * ERS + col * (int)sizeof(T);
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = act_fwd(acc[i][j][4 * q4 + e] + bv[e], a.act, a.slope);
+        for (int e = 0; e < 4; ++e) {
+          float t = acc[i][j][4 * q4 + e];
+          v[e] = act_generic ? t : (t > 0.f ? t : t * ns);
+        }
         if constexpr (sizeof(T) == 2) {
           bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
           *(bf16x4*)dst = o;
@@ -79,6 +107,10 @@ __device__ __forceinline__ void conv_epilogue(const GatherArgs& a, f32x16 (&acc)
   T* yg = (T*)a.y + (size_t)g * a.y_gstride;
   const T* auxg = a.aux ? (const T*)a.aux + (size_t)g * a.y_gstride : nullptr;
   const T* aux2g = a.aux2 ? (const T*)a.aux2 + (size_t)g * a.y_gstride : nullptr;
+  // MUL_ACTGRAD factor from the saved activation output x:  tanh: 1 - x^2;  else  x > 0 ? 1 : gneg
+  const bool epi_add = a.epi == S2P_EPI_ADD;
+  const bool g_tanh = a.gact == S2P_ACT_TANH;
+  const float gneg = a.gact == S2P_ACT_RELU ? 0.f : (a.gact == S2P_ACT_LRELU ? a.gslope : 1.f);
   for (int idx = tid; idx < BPIX * CPR; idx += 256) {
     int row = idx / CPR, ch = idx - row * CPR;
     int off = rowoff[row];
@@ -104,7 +136,8 @@ __device__ __forceinline__ void conv_epilogue(const GatherArgs& a, f32x16 (&acc)
 #pragma unroll
       for (int e = 0; e < CE; ++e) {
         float v = c.get(e), xv = x.get(e);
-        v = (a.epi == S2P_EPI_ADD) ? v + xv : (v + x2.get(e)) * act_grad_from_out(xv, a.gact, a.gslope);
+        float f = g_tanh ? 1.f - xv * xv : (xv > 0.f ? 1.f : gneg);
+        v = epi_add ? v + xv : (v + x2.get(e)) * f;
         c.set(e, v);
       }
     }
@@ -114,6 +147,7 @@ __device__ __forceinline__ void conv_epilogue(const GatherArgs& a, f32x16 (&acc)
         continue;
       }
     }
+    if (a.diag == 6 && c.raw[0] != 0x12345678u) continue;
     if (full) *(u32x4*)(yg + go) = c.raw;
     else for (int e = 0; e < CE; ++e) if (co0 + e < a.Cst) yg[go + e] = from_f32<T>(c.get(e));
   }
@@ -735,9 +769,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
 
   // one linear pipeline over (slab, tap): weights are always one step ahead; the next slab's halo is prefetched
   // into the other halo buffer during the current slab (DBUF) or loaded behind a barrier at the slab boundary.
+  if (a.diag == 5) return;                              // timing ablation: index set-up only
   issue_halo(0, 0);
   issue_w(0, 0, 0);
   __syncthreads();                                     // hipcc drains vmcnt before the barrier
+  if (a.diag == 3) return;                              // timing ablation: prologue only
   int slab = 0, tap = 0;
   for (int kt = 0; kt < nk; ++kt) {
     const int c0 = slab * BK;
@@ -758,19 +794,25 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
       prow[j] = ok ? hb + hp * RS : zrow;
       psw[j] = ok ? (hp >> 1) & 7 : 0;
     }
-    if (a.diag != 2)
+    if (a.diag != 2) {
+      // all 16 fragment reads of the step are issued before its first MFMA (the waits become counted lgkmcnt(N)):
+      // reading per sub-step exposes the LDS latency four times per step
+      bf16x8 af[4][TCO], bf[4][TPIX];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      bf16x8 af[TCO], bf[TPIX];
+      for (int s = 0; s < 4; ++s) {
 #pragma unroll
-      for (int i = 0; i < TCO; ++i) af[i] = *(const bf16x8*)(wrow + i * 32 * RS + (((2 * s + h) ^ swr) * 16));
+        for (int i = 0; i < TCO; ++i) af[s][i] = *(const bf16x8*)(wrow + i * 32 * RS + (((2 * s + h) ^ swr) * 16));
 #pragma unroll
-      for (int j = 0; j < TPIX; ++j) bf[j] = *(const bf16x8*)(prow[j] + (((2 * s + h) ^ psw[j]) * 16));
+        for (int j = 0; j < TPIX; ++j) bf[s][j] = *(const bf16x8*)(prow[j] + (((2 * s + h) ^ psw[j]) * 16));
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < TCO; ++i)
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int j = 0; j < TPIX; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TCO; ++i)
+#pragma unroll
+          for (int j = 0; j < TPIX; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][i], bf[s][j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
     tap = ntap;
@@ -783,6 +825,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
     }
   }
   (void)nk;
+  if (a.diag == 4) { if (acc[0][0][0] == 12345.678f) ((float*)a.y)[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1]; return; }
   conv_epilogue<T, BCO, BPIX, TCO, TPIX>(a, acc, smem, rowoff, g, co_base, wco0, wpix0, r, h, tid);
 }
 
@@ -806,7 +849,8 @@ static int launch_fast(GatherArgs& a, int groups, hipStream_t st) {
       }
       a.halo_lo = lo; a.halo_hi = hi;
       const int npos = BPIX + lo + hi;
-      if (npos <= 176) { hipLaunchKernelGGL((conv_halo_kernel<176, true>), grid, dim3(256), 0, st, a); S2P_CHECK_LAUNCH("conv_halo_kernel"); return 0; }
+      static const int extra_lds = getenv("S2P_HALO_EXTRA_LDS") ? atoi(getenv("S2P_HALO_EXTRA_LDS")) : 0;   // occupancy experiment
+      if (npos <= 176) { hipLaunchKernelGGL((conv_halo_kernel<176, true>), grid, dim3(256), extra_lds, st, a); S2P_CHECK_LAUNCH("conv_halo_kernel"); return 0; }
       if (npos <= 320) { hipLaunchKernelGGL((conv_halo_kernel<320, false>), grid, dim3(256), 0, st, a); S2P_CHECK_LAUNCH("conv_halo_kernel"); return 0; }
     }
   }

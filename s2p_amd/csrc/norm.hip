@@ -49,6 +49,8 @@ __global__ __launch_bounds__(256) void in_reduce_kernel(const NormArgs a) {
     for (int e = 0; e < CE; ++e) q[k][e] = 0.f;
 
   float mean[CE], rstd[CE], gs[CE], bs[CE];
+  // activation selectors resolved once per thread (a per-element switch on a kernel argument is scalar-branch bound)
+  const float gneg = a.act == S2P_ACT_RELU ? 0.f : (a.act == S2P_ACT_LRELU ? a.slope : 1.f);
   if (MODE == 1 && cok) {
 #pragma unroll
     for (int e = 0; e < CE; ++e) {
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256) void in_reduce_kernel(const NormArgs a) {
           float gg = gs[e] + (a.gb ? gv.get(e) : 0.f);
           float bb = bs[e] + (a.gb ? bv.get(e) : 0.f);
           float yv = xh * gg + bb;
-          float dy = dv.get(e) * act_grad_from_out(yv, a.act == S2P_ACT_TANH ? S2P_ACT_NONE : a.act, a.slope);
+          float dy = dv.get(e) * (yv > 0.f ? 1.f : gneg);
           float dxh = dy * gg;
           q[0][e] += dxh; q[1][e] += dxh * xh; q[2][e] += dy * xh; q[3][e] += dy;
         }
@@ -118,6 +120,10 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const NormArgs a) {
   int p_end = p_begin + a.rows_per_split;
   if (p_end > a.HW) p_end = a.HW;
   const float invHW = 1.f / (float)a.HW;
+  // activation selectors resolved once per thread: relu / lrelu / none are  v > 0 ? v : v * ns
+  const float ns = a.act == S2P_ACT_RELU ? 0.f : (a.act == S2P_ACT_LRELU ? a.slope : 1.f);
+  const bool act_generic = a.act == S2P_ACT_TANH || a.act == S2P_ACT_SWISH;
+  const bool g_tanh = a.act == S2P_ACT_TANH;
   float mean[CE], rstd[CE], gs[CE], bs[CE], s1[CE], s2[CE];
 #pragma unroll
   for (int e = 0; e < CE; ++e) {
@@ -148,13 +154,21 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const NormArgs a) {
       float xh = (xv.get(e) - mean[e]) * rstd[e];
       float yv = xh * gg + bb;
       if (MODE == 0) {
-        o0.set(e, act_fwd(yv, a.act, a.slope));
+        o0.set(e, yv > 0.f ? yv : yv * ns);
       } else {
-        float dy = dv.get(e) * act_grad_from_out(yv, a.act, a.slope);
+        float dy = dv.get(e) * (g_tanh ? 1.f - yv * yv : (yv > 0.f ? 1.f : ns));
         float dxh = dy * gg;
         o0.set(e, rstd[e] * (dxh - s1[e] - xh * s2[e]));
         o1.set(e, dy * xh);
         o2.set(e, dy);
+      }
+    }
+    if (MODE == 0 && act_generic) {                   // tanh / swish: rare, one uniform branch per chunk
+#pragma unroll
+      for (int e = 0; e < CE; ++e) {
+        float gg = gs[e] + (gbb ? gv.get(e) : 0.f);
+        float bb = bs[e] + (gbb ? bv.get(e) : 0.f);
+        o0.set(e, act_fwd((xv.get(e) - mean[e]) * rstd[e] * gg + bb, a.act, a.slope));
       }
     }
     *(u32x4*)(yb + (size_t)p * a.y_pitch) = o0.raw;
