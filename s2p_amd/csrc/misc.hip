@@ -403,29 +403,56 @@ extern "C" int s2p_adam_step_dev(float* p, const float* g, float* m, float* v, i
 // fwd: dst_fwd[r][t][c] (row length T*Cpad, zeros for c >= C);  bwd: dst_bwd[c][t][r_off + r] (row length
 // T*Rrow; rows c >= C and columns outside [r_off, r_off+R) are never written: the caller pre-zeroes them once).
 template <typename T>
-__device__ void pack_one(const s2p_pack_job& j, int part, int nparts) {
+__device__ void pack_one(const s2p_pack_job& j, int part, int nparts, float (*tile)[33]) {
+  const int tid = threadIdx.x;
   if (j.dst_fwd) {
-    long long tot = (long long)j.R * j.T * j.Cpad;
     T* d = (T*)j.dst_fwd;
-    for (long long i = (long long)part * 256 + threadIdx.x; i < tot; i += (long long)nparts * 256) {
-      int c = (int)(i % j.Cpad); long long rt = i / j.Cpad;
-      d[i] = from_f32<T>(c < j.C ? j.src[rt * j.C + c] : 0.f);
+    if (j.Cpad == j.C && (j.C & 3) == 0) {
+      // straight cast copy, 4 elements per thread
+      const long long tot4 = (long long)j.R * j.T * j.C / 4;
+      for (long long i = (long long)part * 256 + tid; i < tot4; i += (long long)nparts * 256) {
+        const f32x4 v = *(const f32x4*)(j.src + 4 * i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[4 * i + e] = from_f32<T>(v[e]);
+      }
+    } else {
+      const long long tot = (long long)j.R * j.T * j.Cpad;
+      for (long long i = (long long)part * 256 + tid; i < tot; i += (long long)nparts * 256) {
+        int c = (int)(i % j.Cpad); long long rt = i / j.Cpad;
+        d[i] = from_f32<T>(c < j.C ? j.src[rt * j.C + c] : 0.f);
+      }
     }
   }
   if (j.dst_bwd) {
-    long long tot = (long long)j.C * j.T * j.R;
+    // per tap t: transpose the R x C matrix through a 32 x 32 LDS tile (coalesced fp32 reads along c, contiguous
+    // compute-dtype writes along r)
     T* d = (T*)j.dst_bwd;
-    for (long long i = (long long)part * 256 + threadIdx.x; i < tot; i += (long long)nparts * 256) {
-      int r = (int)(i % j.R); long long ct = i / j.R;
-      int t = (int)(ct % j.T), c = (int)(ct / j.T);
-      d[((long long)c * j.T + t) * j.Rrow + j.r_off + r] = from_f32<T>(j.src[((long long)r * j.T + t) * j.C + c]);
+    const int tr = (j.R + 31) / 32, tc = (j.C + 31) / 32;
+    const long long ntiles = (long long)tr * tc * j.T;
+    const int tx = tid & 31, ty = tid >> 5;              // 32 x 8
+    for (long long q = part; q < ntiles; q += nparts) {
+      const int t = (int)(q % j.T); const long long rc = q / j.T;
+      const int r0 = (int)(rc % tr) * 32, c0 = (int)(rc / tr) * 32;
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        tile[ty + 8 * k][tx] = (r < j.R && c < j.C) ? j.src[((long long)r * j.T + t) * j.C + c] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;
+        if (c < j.C && r < j.R) d[((long long)c * j.T + t) * j.Rrow + j.r_off + r] = from_f32<T>(tile[tx][ty + 8 * k]);
+      }
     }
   }
 }
-__global__ void pack_kernel(const s2p_pack_job* jobs) {
+__global__ __launch_bounds__(256) void pack_kernel(const s2p_pack_job* jobs) {
+  __shared__ float tile[32][33];
   const s2p_pack_job j = jobs[blockIdx.y];
-  if (j.dtype == S2P_F32) pack_one<float>(j, blockIdx.x, gridDim.x);
-  else pack_one<__bf16>(j, blockIdx.x, gridDim.x);
+  if (j.dtype == S2P_F32) pack_one<float>(j, blockIdx.x, gridDim.x, tile);
+  else pack_one<__bf16>(j, blockIdx.x, gridDim.x, tile);
 }
 extern "C" int s2p_pack_weights(const s2p_pack_job* jobs, int n_jobs, int max_elems, void* stream) {
   if (!jobs || n_jobs <= 0) S2P_FAIL(-1, "s2p_pack_weights: bad argument");

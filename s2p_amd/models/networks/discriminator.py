@@ -5,6 +5,8 @@ of 4x4 convs (pad 2, strides 2,2,1 / last two stride 1), LeakyReLU(0.2), Instanc
 intermediate features are returned for the feature-matching loss.  Explicit forward/backward over HIP launches;
 the feature-matching / hinge gradients of the intermediate features are folded into the dgrad epilogue (EPI_ADD).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -136,6 +138,8 @@ class MultiscaleDiscriminator(BaseNetwork):
             d.finalized = True
 
     def _side_stream(self):
+        if os.environ.get("S2P_NO_SIDE_STREAM"):          # A/B switch: everything on the current stream
+            return torch.cuda.current_stream()
         s = getattr(self, "_side", None)
         if s is None:
             s = self._side = torch.cuda.Stream()

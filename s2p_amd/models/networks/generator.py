@@ -9,6 +9,8 @@ restructuring relative to a per-layer eager graph:
   * InstanceNorm + modulation + LeakyReLU is one stats pass + one elementwise pass (s2p_in_*), residual adds are
     fused into the conv epilogue, weight gradients go straight into the flat grad buffer.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -236,6 +238,8 @@ class S2PGenerator(BaseNetwork):
         return out, ctx
 
     def _side_stream(self):
+        if os.environ.get("S2P_NO_SIDE_STREAM"):          # A/B switch: everything on the current stream
+            return torch.cuda.current_stream()
         s = getattr(self, "_side", None)
         if s is None:
             s = self._side = torch.cuda.Stream()
