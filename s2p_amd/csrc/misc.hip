@@ -284,10 +284,29 @@ __device__ __forceinline__ void block_atomic_add(float v, float* out) {
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
 }
+// 16-byte chunks when every pointer is 16-byte aligned (the NHWC activations always are), scalar tail otherwise
+__device__ __forceinline__ bool aligned16(const void* p) { return ((unsigned long long)p & 15ull) == 0ull; }
 template <typename T>
 __global__ void l1_loss_kernel(const T* a, const T* b, long long count, float scale, float* loss, T* grad, int accumulate) {
+  constexpr int CE = DT<T>::CE;
+  const bool vec = aligned16(a) && aligned16(b) && (!grad || aligned16(grad));
+  const long long nch = vec ? count / CE : 0;
   float s = 0.f;
-  GRID_STRIDE(idx, count) {
+  GRID_STRIDE(ci, nch) {
+    Chunk<T> av, bv, gv;
+    av.raw = *(const u32x4*)(a + ci * CE); bv.raw = *(const u32x4*)(b + ci * CE);
+    if (grad && accumulate) gv.raw = *(const u32x4*)(grad + ci * CE);
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+      float d = av.get(e) - bv.get(e);
+      s += fabsf(d);
+      float gsgn = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);
+      if (grad && accumulate) gsgn += gv.get(e);
+      gv.set(e, gsgn);
+    }
+    if (grad) *(u32x4*)(grad + ci * CE) = gv.raw;
+  }
+  for (long long idx = nch * CE + (long long)blockIdx.x * 256 + threadIdx.x; idx < count; idx += (long long)gridDim.x * 256) {
     float d = to_f32(a[idx]) - to_f32(b[idx]);
     s += fabsf(d);
     if (grad) {
@@ -300,7 +319,7 @@ __global__ void l1_loss_kernel(const T* a, const T* b, long long count, float sc
 }
 extern "C" int s2p_l1_loss(int dtype, const void* a, const void* b, int64_t count, float scale, float* loss_out, void* grad_a, int accumulate, void* stream) {
   if (!a || !b || !loss_out) S2P_FAIL(-1, "s2p_l1_loss: null pointer");
-  dim3 g(grid_for(count, 1024));
+  dim3 g(grid_for(count / 4, 2048));
   if (dtype == S2P_F32) hipLaunchKernelGGL(l1_loss_kernel<float>, g, dim3(256), 0, (hipStream_t)stream, (const float*)a, (const float*)b, (long long)count, scale, loss_out, (float*)grad_a, accumulate);
   else if (dtype == S2P_BF16) hipLaunchKernelGGL(l1_loss_kernel<__bf16>, g, dim3(256), 0, (hipStream_t)stream, (const __bf16*)a, (const __bf16*)b, (long long)count, scale, loss_out, (__bf16*)grad_a, accumulate);
   else S2P_FAIL(-1, "s2p_l1_loss: bad dtype");
@@ -491,7 +510,17 @@ extern "C" int s2p_scale(int dtype, void* x, int64_t n, const float* scale, void
 // ---- elementwise add and channel-slice copy ---------------------------------------------------------------
 template <typename T>
 __global__ void add_kernel(const T* a, const T* b, T* out, long long n) {
-  GRID_STRIDE(idx, n) out[idx] = from_f32<T>(to_f32(a[idx]) + to_f32(b[idx]));
+  constexpr int CE = DT<T>::CE;
+  const long long nch = (aligned16(a) && aligned16(b) && aligned16(out)) ? n / CE : 0;
+  GRID_STRIDE(ci, nch) {
+    Chunk<T> av, bv;
+    av.raw = *(const u32x4*)(a + ci * CE); bv.raw = *(const u32x4*)(b + ci * CE);
+#pragma unroll
+    for (int e = 0; e < CE; ++e) av.set(e, av.get(e) + bv.get(e));
+    *(u32x4*)(out + ci * CE) = av.raw;
+  }
+  for (long long idx = nch * CE + (long long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long long)gridDim.x * 256)
+    out[idx] = from_f32<T>(to_f32(a[idx]) + to_f32(b[idx]));
 }
 extern "C" int s2p_add(int dtype, const void* a, const void* b, void* out, int64_t n, void* stream) {
   if (dtype == S2P_F32) hipLaunchKernelGGL(add_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)a, (const float*)b, (float*)out, (long long)n);
