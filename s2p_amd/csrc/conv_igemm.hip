@@ -16,6 +16,7 @@
 
 #define MAX_TAPS 64
 
+constexpr int PHASE_TAPS = 16, MAX_PHASES = 4;
 struct GatherArgs {
   const void* x; const void* w; const float* bias; const void* aux; const void* aux2; void* y;
   int M, Hi, Wi, Qh, Qw;
@@ -33,6 +34,10 @@ struct GatherArgs {
   int splitk, ksteps;          // generic fp32 path only: split-K over blockIdx.z with fp32 atomics into a zeroed y
   unsigned x_bytes, w_bytes;   // fast path: buffer-descriptor sizes of the gathered tensor / packed weights (per group view)
   int tap[MAX_TAPS];   // (wt << 16) | ((dx & 0xff) << 8) | (dy & 0xff)
+  // merged sub-pixel phases (strided dgrad / transposed fwd on the LDS-DMA kernel): blockIdx.z selects a record that
+  // overrides the per-phase fields above, so the s*s short GEMMs of one layer are ONE launch
+  int nphase;
+  struct Phase { int Qh, Qw, M, oy0, ox0, T, Ktot, npix_tiles; int tap[PHASE_TAPS]; } ph[MAX_PHASES];
 };
 
 template <typename T> struct Mma;
@@ -48,7 +53,7 @@ __device__ __forceinline__ void conv_epilogue(const GatherArgs& a, f32x16 (&acc)
   // The activation / epilogue selectors are kernel arguments; they are resolved ONCE per wave here (uniform
   // selects of a negative-side slope), never per element: a per-element switch costs ~6 us per launch in scalar
   // branches and instruction fetch.  relu / lrelu / none all are  v > 0 ? v : v * ns  with ns = 0 / slope / 1.
-  const float* bias = (a.bias && blockIdx.z == 0) ? a.bias + (size_t)g * a.Cout : nullptr;
+  const float* bias = (a.bias && (blockIdx.z == 0 || a.nphase > 0)) ? a.bias + (size_t)g * a.Cout : nullptr;   // z: split-K slice or phase
   const bool act_generic = (a.act == S2P_ACT_TANH || a.act == S2P_ACT_SWISH);
   const float ns = a.act == S2P_ACT_RELU ? 0.f : (a.act == S2P_ACT_LRELU ? a.slope : 1.f);
   if (bias) {
@@ -524,21 +529,30 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const GatherArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int g = blockIdx.y;
-  int nblk = a.npix_tiles * a.nco_tiles;
+  // per-phase problem fields (block-uniform)
+  int pQh = a.Qh, pQw = a.Qw, pM = a.M, poy0 = a.oy0, pox0 = a.ox0, pT = a.T, pKtot = a.Ktot, pnpt = a.npix_tiles;
+  const int* ptap = a.tap;
+  if (a.nphase > 0) {
+    const GatherArgs::Phase& P = a.ph[blockIdx.z];
+    pQh = P.Qh; pQw = P.Qw; pM = P.M; poy0 = P.oy0; pox0 = P.ox0; pT = P.T; pKtot = P.Ktot; pnpt = P.npix_tiles;
+    ptap = P.tap;
+  }
+  int nblk = pnpt * a.nco_tiles;
   int bid = blockIdx.x;
+  if (bid >= nblk) return;                            // phases differ in size; the grid is sized for the largest
   {
     int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, k = bid >> 3;
     bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
   }
   const int co_tile = bid % a.nco_tiles, pix_tile = bid / a.nco_tiles;
   const int co_base = co_tile * BCO, pix_base = pix_tile * BPIX;
-  const int QQ = a.Qh * a.Qw;
+  const int QQ = pQh * pQw;
   if (tid < BPIX) {
     int m = pix_base + tid;
     int off = -1;
-    if (m < a.M) {
-      int n = m / QQ, rr = m - n * QQ, qy = rr / a.Qw, qx = rr - qy * a.Qw;
-      off = ((n * a.Ho + qy * a.ostride + a.oy0) * a.Wo + qx * a.ostride + a.ox0);
+    if (m < pM) {
+      int n = m / QQ, rr = m - n * QQ, qy = rr / pQw, qx = rr - qy * pQw;
+      off = ((n * a.Ho + qy * a.ostride + poy0) * a.Wo + qx * a.ostride + pox0);
     }
     rowoff[tid] = off;
   }
@@ -568,12 +582,12 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const GatherArgs a) {
     int m = pix_base + row - BCO;
     unsigned long long mask = 0ull;
     unsigned byte = 0u;
-    if (m < a.M) {
-      int n = m / QQ, rr = m - n * QQ, qy = rr / a.Qw, qx = rr - qy * a.Qw;
+    if (m < pM) {
+      int n = m / QQ, rr = m - n * QQ, qy = rr / pQw, qx = rr - qy * pQw;
       int py = qy * a.istride, px = qx * a.istride;
       byte = (unsigned)(((n * a.Hi + py) * a.Wi + px) * a.x_pitch * 2 + c * 16);
-      for (int t = 0; t < a.T; ++t) {
-        int ti = a.tap[t];
+      for (int t = 0; t < pT; ++t) {
+        int ti = ptap[t];
         int iy = py + (int)(signed char)(ti & 0xff), ix = px + (int)(signed char)((ti >> 8) & 0xff);
         if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) mask |= 1ull << t;
       }
@@ -581,12 +595,12 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const GatherArgs a) {
     p_byte[i] = byte; p_mask[i] = mask;
   }
 
-  const int nk = a.Ktot / BK;
+  const int nk = pKtot / BK;
   int tap = 0, c0 = 0;                                // block-uniform K position
   typedef __attribute__((address_space(3))) void* lds_ptr;
 
   auto issue = [&](int buf) {
-    const int ti = a.tap[tap];
+    const int ti = ptap[tap];
     const int dy = (int)(signed char)(ti & 0xff), dx = (int)(signed char)((ti >> 8) & 0xff), wt = ti >> 16;
     const int toff = ((dy * a.Wi + dx) * a.x_pitch + c0) * 2;
     const int woff = (wt * a.Cin + c0) * 2;
@@ -922,6 +936,58 @@ static int run_scatter(const Geo& G, const void* x, const void* w, const float* 
                        const void* aux2, void* y,
                        int act, float slope, int epi, int gact, float gslope, hipStream_t st) {
   const int s = G.stride;
+  if constexpr (sizeof(T) == 2) {
+    // all s*s phases in ONE launch of the LDS-DMA kernel (blockIdx.z = phase) when that kernel applies
+    static const int no_merge = (getenv("S2P_NO_PHASE_MERGE") || getenv("S2P_NO_LDS_DMA")) ? 1 : 0;
+    const long long xb = (long long)G.N * G.Hi * G.Wi * G.xp * 2, wb = (long long)G.Co * G.w_row * 2;
+    if (!no_merge && s * s <= MAX_PHASES && s > 1 && G.Ci % 64 == 0 && xb < (1ll << 31) && wb < (1ll << 31) && G.Cst > 32) {
+      GatherArgs a{};
+      a.x = x; a.w = w; a.bias = bias; a.aux = aux; a.aux2 = aux2; a.y = y;
+      a.Hi = G.Hi; a.Wi = G.Wi;
+      a.Cin = G.Ci; a.x_pitch = G.xp; a.x_gstride = G.xg;
+      a.Cout = G.Co; a.Cst = G.Cst; a.y_pitch = G.yp; a.y_gstride = G.yg;
+      a.Ho = G.Ho; a.Wo = G.Wo; a.istride = 1; a.ostride = s;
+      a.w_row = G.w_row; a.w_gstride = G.w_gstride;
+      a.reflect = 0; a.act = act; a.epi = epi; a.slope = slope; a.gact = gact; a.gslope = gslope;
+      a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
+      static const int diag = getenv("S2P_DIAG") ? atoi(getenv("S2P_DIAG")) : 0;
+      a.diag = diag;
+      bool ok = true;
+      int np = 0, max_npt = 0;
+      for (int py = 0; py < s && ok; ++py)
+        for (int px = 0; px < s && ok; ++px) {
+          GatherArgs::Phase& P = a.ph[np];
+          P.Qh = (G.Ho - py + s - 1) / s; P.Qw = (G.Wo - px + s - 1) / s;
+          if (P.Qh <= 0 || P.Qw <= 0) continue;
+          P.M = G.N * P.Qh * P.Qw; P.oy0 = py; P.ox0 = px;
+          int t = 0;
+          for (int ky = 0; ky < G.KH; ++ky) {
+            if ((py + G.pad - ky) % s != 0) continue;
+            for (int kx = 0; kx < G.KW; ++kx) {
+              if ((px + G.pad - kx) % s != 0) continue;
+              if (t >= PHASE_TAPS) { ok = false; break; }
+              P.tap[t++] = pack_tap((py + G.pad - ky) / s, (px + G.pad - kx) / s, ky * G.KW + kx);
+            }
+            if (!ok) break;
+          }
+          if (t == 0) ok = false;                      // a phase without taps still has to store zeros / bias: generic path
+          P.T = t; P.Ktot = t * G.Ci;
+          P.npix_tiles = cdiv(P.M, 128);
+          if (P.npix_tiles > max_npt) max_npt = P.npix_tiles;
+          ++np;
+        }
+      if (ok && np > 0) {
+        a.nphase = np;
+        const int BCO = a.Cst > 64 ? 128 : 64;
+        a.nco_tiles = cdiv(a.Cst, BCO);
+        dim3 grid(max_npt * a.nco_tiles, G.groups, np);
+        if (BCO == 128) hipLaunchKernelGGL((conv_dma_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_dma_kernel<64, 128, 2, 2>), grid, dim3(256), 0, st, a);
+        S2P_CHECK_LAUNCH("conv_dma_kernel(phases)");
+        return 0;
+      }
+    }
+  }
   for (int py = 0; py < s; ++py)
     for (int px = 0; px < s; ++px) {
       GatherArgs a{};
