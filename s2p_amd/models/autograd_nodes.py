@@ -131,13 +131,16 @@ class _GLossNode(torch.autograd.Function):
                 tap_grads.append(tg)
         ctx.model, ctx.dctx, ctx.grads, ctx.vctx, ctx.tap_grads, ctx.d_fake, ctx.N = \
             model, dctx, grads, vctx, tap_grads, d_fake, N
-        return losses
+        # one zero-dim output per loss term (not one [4] tensor indexed by the caller): the trainer's
+        # sum(losses.values()).mean().backward() then costs no select-backward zero-fill / copy / accumulate kernels
+        return tuple(losses.unbind(0))
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *gs_in):
         model, N = ctx.model, ctx.N
         if not model.assume_unit_loss_grad:
             # general case: scale each loss's gradient seeds by its upstream gradient (device scalars, no host sync)
+            g = torch.stack([gi.float() if gi is not None else torch.zeros((), device=ctx.d_fake.device) for gi in gs_in])
             for gs in ctx.grads:
                 ops.scale_(gs[-1], g[0:1])
                 for t in gs[:-1]:
@@ -179,19 +182,21 @@ class _DLossNode(torch.autograd.Function):
             g[-1] = _hinge_seed(feats[-1], 0, 1, N, num_D, losses[0:1], losses[1:2])
             grads.append(g)
         ctx.model, ctx.dctx, ctx.grads, ctx.N = model, dctx, grads, N
-        return losses
+        return tuple(losses.unbind(0))
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *gs_in):
         model = ctx.model
+        dev = ctx.grads[0][-1].device
         if not model.assume_unit_loss_grad:
+            g = torch.stack([gi.float() if gi is not None else torch.zeros((), device=dev) for gi in gs_in])
             for gs in ctx.grads:
                 t = gs[-1]
                 half = t.numel() // 2
                 flat = t.view(-1)
                 ops.scale_(flat[:half], g[0:1])
                 ops.scale_(flat[half:], g[1:2])
-        ops.arena_begin(g.device)
+        ops.arena_begin(dev)
         model.netD.bwd_nhwc(ctx.dctx, ctx.grads, need_wgrad=True, need_dx=False)
         ctx.dctx = ctx.grads = None
         return None, None, None, None, None
