@@ -319,7 +319,10 @@ __global__ void l1_loss_kernel(const T* a, const T* b, long long count, float sc
 }
 extern "C" int s2p_l1_loss(int dtype, const void* a, const void* b, int64_t count, float scale, float* loss_out, void* grad_a, int accumulate, void* stream) {
   if (!a || !b || !loss_out) S2P_FAIL(-1, "s2p_l1_loss: null pointer");
-  dim3 g(grid_for(count / 4, 2048));
+  // every workgroup ends in ONE atomicAdd on the same loss word, and same-address atomics retire at ~13 ns each on
+  // MI355X (2048 workgroups = a 29 us floor): 512 workgroups of 16-byte loads still saturate HBM
+  static const int l1_cap = getenv("S2P_L1_BLOCKS") ? atoi(getenv("S2P_L1_BLOCKS")) : 512;
+  dim3 g(grid_for(count / 4, l1_cap));
   if (dtype == S2P_F32) hipLaunchKernelGGL(l1_loss_kernel<float>, g, dim3(256), 0, (hipStream_t)stream, (const float*)a, (const float*)b, (long long)count, scale, loss_out, (float*)grad_a, accumulate);
   else if (dtype == S2P_BF16) hipLaunchKernelGGL(l1_loss_kernel<__bf16>, g, dim3(256), 0, (hipStream_t)stream, (const __bf16*)a, (const __bf16*)b, (long long)count, scale, loss_out, (__bf16*)grad_a, accumulate);
   else S2P_FAIL(-1, "s2p_l1_loss: bad dtype");
@@ -343,7 +346,7 @@ __global__ void hinge_kernel(const T* x, long long count, int mode, float scale,
 }
 extern "C" int s2p_hinge_loss(int dtype, const void* x, int64_t count, int mode, float scale, float* loss_out, void* grad_x, void* stream) {
   if (!x || !loss_out || mode < 0 || mode > 2) S2P_FAIL(-1, "s2p_hinge_loss: bad argument");
-  dim3 g(grid_for(count, 1024));
+  dim3 g(grid_for(count, 256));                         // same-address atomic per workgroup: keep the grid small
   if (dtype == S2P_F32) hipLaunchKernelGGL(hinge_kernel<float>, g, dim3(256), 0, (hipStream_t)stream, (const float*)x, (long long)count, mode, scale, loss_out, (float*)grad_x);
   else if (dtype == S2P_BF16) hipLaunchKernelGGL(hinge_kernel<__bf16>, g, dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (long long)count, mode, scale, loss_out, (__bf16*)grad_x);
   else S2P_FAIL(-1, "s2p_hinge_loss: bad dtype");
