@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--size", type=int, default=84)
     ap.add_argument("--env_type", type=str, default="cheetah")
@@ -47,6 +47,36 @@ def parse():
     ap.add_argument("--backend", type=str, default="", help="torch.distributed backend (default nccl = RCCL; gloo for a 1-GPU rehearsal)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use GPU 0")
     return ap.parse_args()
+
+
+def spade_resblk_aggregate(recs, N, HW):
+    """north_star's named target: all launches of the 6 SPADE/MAT ResBlks of ONE generator forward + backward
+    (block convs, the fused gamma/beta and shared convs of the 12 MAT norms, the IN/MAT kernels).  The step runs
+    the generator forward twice (G step, D step), so forward-kind launches are halved."""
+    h = HW // 4
+    def ms(r): return r["events"][0].elapsed_time(r["events"][1])
+    conv_shapes = {(N, h, h, 256, 256, 3, 1, 1, 0), (N, h, h, 128, 512, 3, 1, 12, 0), (N, h, h, 3, 1536, 3, 1, 1, 0)}
+    flops = t_mfma = t_norm = nbytes = 0.0
+    launches = 0
+    for r in recs:
+        k = r["kind"]
+        if k in ("fwd", "dgrad", "wgrad") and tuple(r["shape"]) in conv_shapes:
+            w = 0.5 if k == "fwd" else 1.0
+            flops += w * r["flops"]; t_mfma += w * ms(r); launches += w
+        elif k.startswith("norm") and tuple(r["shape"][:4]) == (N, h, h, 256) and r["shape"][4] == 1 or \
+                (k == "norm_stats" and tuple(r["shape"][:4]) == (N, h, h, 256)):
+            w = 1.0 if k == "norm_bwd" else 0.5
+            nbytes += w * r["bytes"]; t_norm += w * ms(r); launches += w
+    if t_mfma <= 0:
+        return None
+    tot = t_mfma + t_norm
+    return dict(gflop=round(flops / 1e9, 1), ms=round(tot, 3), mfma_ms=round(t_mfma, 3), norm_ms=round(t_norm, 3),
+                launches=int(launches), tflops=round(flops / (tot * 1e-3) / 1e12, 2),
+                frac=round(flops / (tot * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                mfma_only_frac=round(flops / (t_mfma * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                norm_hbm_tbps=round(nbytes / (t_norm * 1e-3) / 1e12, 2) if t_norm > 0 else None,
+                includes="6 blocks: 12 conv3x3 256->256 (fwd, dgrad, wgrad), grouped gamma/beta conv 12x(128->512) (fwd, dgrad, wgrad), "
+                         "shared conv 3->1536 (fwd, wgrad), 24 IN-stats + 24 MAT-apply halves, 12 MAT backward pairs; the fp32 state affine is excluded")
 
 
 def cpu_baseline(args, state_dim):
@@ -219,9 +249,12 @@ def main():
         ops.PROFILE = []
         eager_step()
         torch.cuda.synchronize()
-        recs, ops.PROFILE = ops.PROFILE, None
+        all_recs, ops.PROFILE = ops.PROFILE, None
     if not args.no_roofline and rank == 0:
-        print("[bench] roofline leg done (%d conv launches)" % len(recs), file=sys.stderr, flush=True)
+        recs = [r for r in all_recs if r["kind"] in ("fwd", "dgrad", "wgrad")]
+        print("[bench] roofline leg done (%d conv launches, %d norm launches)" % (len(recs), len(all_recs) - len(recs)),
+              file=sys.stderr, flush=True)
+        resblk = spade_resblk_aggregate(all_recs, args.batch, 84)
         tot_f = sum(r["flops"] for r in recs)
         tot_ms = sum(r["events"][0].elapsed_time(r["events"][1]) for r in recs)
         by_kind = {}
@@ -240,7 +273,7 @@ def main():
                         tflops=round(dv[0] / (dv[1] * 1e-3) / 1e12, 2), frac=round(dv[0] / (dv[1] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4))
         roofline = dict(bound="mfma", kernel="implicit-GEMM conv family: conv_halo/conv_dma/conv_gather (fwd, dgrad) + wgrad_dma/wgrad "
                                              "+ thin_tiled kernels, all %d launches of one step" % len(recs),
-                        dominant_layer=dominant,
+                        dominant_layer=dominant, spade_resblk_fwd_bwd=resblk,
                         achieved=round(ach, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                         traffic=None, algorithmic_gflop_per_step=round(tot_f / 1e9, 1), conv_ms_per_step=round(tot_ms, 3),
                         avg_launch_us=round(tot_ms * 1e3 / max(len(recs), 1), 2),

@@ -61,6 +61,25 @@ class _Prof:
             PROFILE.append(self.rec)
 
 
+class _ProfNorm:
+    """Same hook for the IN / MAT kernels: algorithmic HBM bytes instead of FLOPs."""
+
+    def __init__(self, kind, x, C, nbytes, modulated):
+        self.on = PROFILE is not None
+        if self.on:
+            N, H, W, _ = x.shape
+            self.rec = dict(kind=kind, flops=0.0, bytes=float(nbytes), shape=(N, H, W, C, int(modulated)), dtype=str(x.dtype))
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def done(self):
+        if self.on:
+            self.e1.record()
+            self.rec["events"] = (self.e0, self.e1)
+            PROFILE.append(self.rec)
+
+
 def pad_to(c, ce):
     return (c + ce - 1) // ce * ce
 
@@ -158,7 +177,9 @@ def channel_sum(dy, C, db):
 def in_stats(x, C):
     N, H, W, xp = x.shape
     stats = zeros_f32((N, C, 2), x.device)
+    pr = _ProfNorm("norm_stats", x, C, N * H * W * C * x.element_size(), False)
     check(lib().s2p_in_stats(dtype_id(x.dtype), ptr(x), N, H * W, C, xp, IN_EPS, ptr(stats), stream()), "s2p_in_stats")
+    pr.done()
     return stats
 
 
@@ -175,8 +196,10 @@ def in_apply_fwd(x, C, stats, gb=None, gb_off=0, gb_st=None, st_off=0, act=ACT_N
     N, H, W, xp = x.shape
     y = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
     gbp, gb_pitch, stp, st_pitch = _gb_args(gb, gb_off, gb_st, st_off)
+    pr = _ProfNorm("norm_fwd", x, C, N * H * W * C * x.element_size() * (4 if gb is not None else 2), gb is not None)
     check(lib().s2p_in_apply_fwd(dtype_id(x.dtype), ptr(x), N, H * W, C, xp, ptr(stats), gbp, gb_pitch, stp, st_pitch,
                                  act, slope, IN_EPS, ptr(y), C, stream()), "s2p_in_apply_fwd")
+    pr.done()
     return y
 
 
@@ -187,6 +210,9 @@ def in_bwd(da, x, C, stats, gb=None, gb_off=0, gb_st=None, st_off=0, act=ACT_NON
     sums = zeros_f32((N, C, 4), x.device)
     gbp, gb_pitch, stp, st_pitch = _gb_args(gb, gb_off, gb_st, st_off)
     dt = dtype_id(x.dtype)
+    el = N * H * W * C * x.element_size()
+    # reduce reads x, da (+gamma, beta); apply reads the same and writes dx (+dgamma, dbeta)
+    pr = _ProfNorm("norm_bwd", x, C, el * ((4 + 4 + 3) if gb is not None else (2 + 2 + 1)), gb is not None)
     check(lib().s2p_in_bwd_reduce(dt, ptr(da), da.shape[3], ptr(x), N, H * W, C, xp, ptr(stats), gbp, gb_pitch, stp,
                                   st_pitch, act, slope, IN_EPS, ptr(sums), stream()), "s2p_in_bwd_reduce")
     dx = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
@@ -194,6 +220,7 @@ def in_bwd(da, x, C, stats, gb=None, gb_off=0, gb_st=None, st_off=0, act=ACT_NON
     check(lib().s2p_in_bwd_apply(dt, ptr(da), da.shape[3], ptr(x), N, H * W, C, xp, ptr(stats), gbp, gb_pitch, stp,
                                  st_pitch, act, slope, IN_EPS, ptr(sums), ptr(dx), C, dgbp,
                                  dgb.shape[3] if dgb is not None else 0, stream()), "s2p_in_bwd_apply")
+    pr.done()
     return dx, sums
 
 
