@@ -72,8 +72,8 @@ def randomize(params, seed, gain):
     return out
 
 
-def build(precision, tmp_path, extra=()):
-    args = ["--env_type", "cheetah", "--batchSize", "2", "--precision", precision, "--gpu_ids", "0",
+def build(precision, tmp_path, extra=(), env="cheetah"):
+    args = ["--env_type", env, "--batchSize", "2", "--precision", precision, "--gpu_ids", "0",
             "--checkpoints_dir", str(tmp_path)] + list(extra)
     opt = TrainOptions().parse(args, quiet=True)
     model = Pix2PixModel(opt)
@@ -109,6 +109,18 @@ def test_generator_forward_backward(hip_device, tmp_path, precision, tol, gtol, 
     worst = sorted(errs.items(), key=lambda kv: -kv[1][0])[:5]
     print("worst grad rel-L2 errors (hip, fp32-oracle) vs fp64:", precision, worst)
     check_grads(errs, gtol, frac)
+
+
+def test_walker_state_dim_forward(hip_device, tmp_path):
+    """BASELINE.json configs[3]: walker env, 24-dim state (posenc width 24*21 = 504), odd batch of 3."""
+    opt, model, spec, pg, pd, pv = build("fp32", tmp_path, env="walker")
+    assert opt.state_dim == 24 and spec.state_dim == 24
+    prev, state, real = make_inputs(3, 84, 84, 24, seed=9)
+    with torch.no_grad():
+        y = model.netG(prev.cuda(), state.cuda())
+        y_ref = O.generator_forward(pg, prev, state, spec)
+    assert y.shape == y_ref.shape == (3, 3, 84, 84)
+    assert rel(y.cpu(), y_ref) < 1e-3
 
 
 @pytest.mark.parametrize("precision,tol,gtol", [("fp32", 2e-3, 2e-2), ("bf16", 8e-2, 0.7)])
