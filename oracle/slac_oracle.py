@@ -1,8 +1,9 @@
 """CPU oracle for the SLAC encoder / decoder conv stacks -- TEST INFRASTRUCTURE ONLY.
 
 Restates `/root/reference/rlkit/torch/slac/network/latent.py`: Decoder (:55-113, image_size 100 branch :82-101) and
-Encoder (:116-171, image_size 100 branch :141-160).  PINNED by tests/golden/slac_golden_v1.npz: outputs of the REAL
-reference modules loaded with the seeded weights of `make_params` (tests/golden/make_golden_slac.py).
+Encoder (:116-171, image_size 100 branch :141-160).  PINNED by tests/golden/slac_golden_v1.npz (forward) and
+tests/golden/slac_bwd_golden_v1.npz (parameter / latent gradients): outputs of the REAL reference modules loaded with
+the seeded weights of `make_params` (tests/golden/make_golden_slac.py, make_golden_slac_bwd.py).
 """
 import torch
 import torch.nn.functional as F
@@ -48,3 +49,15 @@ def decoder_forward(p, z):
     B, S, L = z.shape
     y = run_stack(DECODER_100, p, z.reshape(B * S, L, 1, 1))
     return y.reshape(B, S, *y.shape[1:])
+
+
+def backward_case(seed_in, seed_r):
+    """Seeded inputs and upstream gradients of the backward fixture (shared by the fixture generator and the tests):
+    frames x [2,2,3,100,100] in [0,1] on the uint8 grid, latents z [2,2,288], d(loss)/d(feat), d(loss)/d(img)."""
+    g = torch.Generator().manual_seed(seed_in)
+    x = (torch.rand(2, 2, 3, 100, 100, generator=g) * 255).round() / 255.0
+    z = torch.randn(2, 2, 288, generator=g)
+    g = torch.Generator().manual_seed(seed_r)
+    r_feat = torch.randn(2, 2, 256, generator=g)
+    r_img = torch.randn(2, 2, 3, 100, 100, generator=g) * 0.05
+    return x, z, r_feat, r_img
