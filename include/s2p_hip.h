@@ -206,6 +206,14 @@ int s2p_add(int dtype, const void* a, const void* b, void* out, int64_t n, void*
 int s2p_copy_channels(int dtype, const void* src, int src_pitch, int src_off, void* dst,
                       int dst_pitch, int dst_off, int C, int64_t pixels, int accumulate, void* stream);
 
+/* ---- image-fidelity metrics (the paper's PSNR / SSIM, rebuttal.md:50 -- no reference code) ----
+ * a, b: fp32 NCHW [N,C,H,W].  sq_err_sum[n] += sum over the image of (a-b)^2;  ssim_sum[n] += sum over channels and
+ * over the (H-10)x(W-10) fully covered positions of the 11x11 Gaussian-window (sigma 1.5) SSIM index with
+ * C1 = (0.01 R)^2, C2 = (0.03 R)^2, R = data_range.  Both accumulators are caller-zeroed fp32 [N].
+ * PSNR = 10 log10(R^2 C H W / sq_err_sum);  SSIM = ssim_sum / (C (H-10) (W-10)).  Requires H, W >= 11.            */
+int s2p_image_metrics(const float* a, const float* b, int N, int C, int H, int W, float data_range,
+                      float* sq_err_sum, float* ssim_sum, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,7 @@ SIGNATURES = {
     "s2p_scale": [c_int, _P, c_int64, _P, _P],
     "s2p_add": [c_int, _P, _P, _P, c_int64, _P],
     "s2p_copy_channels": [c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int64, c_int, _P],
+    "s2p_image_metrics": [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P],
 }
 _RESTYPE = {"s2p_last_error": ctypes.c_char_p}
 

@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=libs2p_hip.so
-SRCS="conv_igemm.hip wgrad_igemm.hip norm.hip misc.hip thin_conv.hip"
+SRCS="conv_igemm.hip wgrad_igemm.hip norm.hip misc.hip thin_conv.hip metrics.hip"
 newest=$(ls -t $SRCS s2p_common.h ../../include/s2p_hip.h build.sh | head -1)
 if [ -f "$OUT" ] && [ "$OUT" -nt "$newest" ]; then exit 0; fi
 pids=()
@@ -12,5 +12,5 @@ for s in $SRCS; do
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" conv_igemm.o wgrad_igemm.o norm.o misc.o thin_conv.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" conv_igemm.o wgrad_igemm.o norm.o misc.o thin_conv.o metrics.o
 echo "built $(pwd)/$OUT"

@@ -8,6 +8,7 @@ import numpy as np
 import torch
 
 from s2p_amd.data import S2PDataset, tensor_to_images
+from s2p_amd.metrics import image_metrics
 from s2p_amd.models.pix2pix_model import Pix2PixModel
 from s2p_amd.options.test_options import TestOptions
 from s2p_amd.rollout import rollout
@@ -23,6 +24,10 @@ def main(args=None):
     gt = frames[1:]
     l1 = float((gen.cpu() - gt).abs().mean())
     print("N-step generation: env=%s start_idx=%d seq_len=%d  mean|gen-gt|=%.4f" % (opt.env_type, opt.start_idx, opt.seq_len, l1))
+    if gen.shape[-1] >= 11 and gen.shape[-2] >= 11:          # the paper's fidelity metrics, per generated step (on device)
+        psnr, ssim = image_metrics(gen, gt.to(gen.device))
+        print("  PSNR per step (dB):", " ".join("%.2f" % v for v in psnr.tolist()))
+        print("  SSIM per step     :", " ".join("%.4f" % v for v in ssim.tolist()))
     os.makedirs(opt.results_dir, exist_ok=True)
     top = np.concatenate(list(tensor_to_images(gen)), axis=1)
     bot = np.concatenate(list(tensor_to_images(gt)), axis=1)
