@@ -51,12 +51,23 @@ __global__ __launch_bounds__(256) void in_reduce_kernel(const NormArgs a) {
   float mean[CE], rstd[CE], gs[CE], bs[CE];
   // activation selectors resolved once per thread (a per-element switch on a kernel argument is scalar-branch bound)
   const float gneg = a.act == S2P_ACT_RELU ? 0.f : (a.act == S2P_ACT_LRELU ? a.slope : 1.f);
-  if (MODE == 1 && cok) {
+  if (MODE == 1) {
+    // per-(n, channel) constants: computed by 64 threads once per workgroup and shared through LDS (a thread walks
+    // only a few pixels, so 4*CE global loads + CE rsqrt per thread would cost as much as its payload)
+    __shared__ float cst[4][CS];
+    if (tid < CS) {
+      const int c = blockIdx.x * CS + tid;
+      float m = 0.f, r = 0.f, g1 = 1.f, b1 = 0.f;
+      if (c < a.C) {
+        mean_rstd(a.stats, n, a.C, c, a.HW, a.eps, m, r);
+        if (a.gbst) { g1 = 1.f + a.gbst[(size_t)n * a.gbst_pitch + c]; b1 = a.gbst[(size_t)n * a.gbst_pitch + a.C + c]; }
+      }
+      cst[0][tid] = m; cst[1][tid] = r; cst[2][tid] = g1; cst[3][tid] = b1;
+    }
+    __syncthreads();
 #pragma unroll
     for (int e = 0; e < CE; ++e) {
-      mean_rstd(a.stats, n, a.C, c0 + e, a.HW, a.eps, mean[e], rstd[e]);
-      gs[e] = 1.f + (a.gbst ? a.gbst[(size_t)n * a.gbst_pitch + c0 + e] : 0.f);
-      bs[e] = a.gbst ? a.gbst[(size_t)n * a.gbst_pitch + a.C + c0 + e] : 0.f;
+      mean[e] = cst[0][cc * CE + e]; rstd[e] = cst[1][cc * CE + e]; gs[e] = cst[2][cc * CE + e]; bs[e] = cst[3][cc * CE + e];
     }
   }
   if (cok) {
@@ -115,11 +126,24 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const NormArgs a) {
   constexpr int CS = 64, NCH = CS / CE, PR = 256 / NCH;
   const int tid = threadIdx.x, cc = tid % NCH, pr = tid / NCH;
   const int n = blockIdx.y, c0 = blockIdx.x * CS + cc * CE;
-  if (c0 >= a.C) return;
   const int p_begin = blockIdx.z * a.rows_per_split;
   int p_end = p_begin + a.rows_per_split;
   if (p_end > a.HW) p_end = a.HW;
   const float invHW = 1.f / (float)a.HW;
+  // per-(n, channel) constants once per workgroup through LDS (see in_reduce_kernel)
+  __shared__ float cst[6][CS];
+  if (tid < CS) {
+    const int c = blockIdx.x * CS + tid;
+    float m = 0.f, r = 0.f, g1 = 1.f, b1 = 0.f, q1 = 0.f, q2 = 0.f;
+    if (c < a.C) {
+      mean_rstd(a.stats, n, a.C, c, a.HW, a.eps, m, r);
+      if (a.gbst) { g1 = 1.f + a.gbst[(size_t)n * a.gbst_pitch + c]; b1 = a.gbst[(size_t)n * a.gbst_pitch + a.C + c]; }
+      if (MODE == 1) { const float* sm = a.sums + ((size_t)n * a.C + c) * 4; q1 = sm[0] * invHW; q2 = sm[1] * invHW; }
+    }
+    cst[0][tid] = m; cst[1][tid] = r; cst[2][tid] = g1; cst[3][tid] = b1; cst[4][tid] = q1; cst[5][tid] = q2;
+  }
+  __syncthreads();
+  if (c0 >= a.C) return;
   // activation selectors resolved once per thread: relu / lrelu / none are  v > 0 ? v : v * ns
   const float ns = a.act == S2P_ACT_RELU ? 0.f : (a.act == S2P_ACT_LRELU ? a.slope : 1.f);
   const bool act_generic = a.act == S2P_ACT_TANH || a.act == S2P_ACT_SWISH;
@@ -127,13 +151,9 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const NormArgs a) {
   float mean[CE], rstd[CE], gs[CE], bs[CE], s1[CE], s2[CE];
 #pragma unroll
   for (int e = 0; e < CE; ++e) {
-    mean_rstd(a.stats, n, a.C, c0 + e, a.HW, a.eps, mean[e], rstd[e]);
-    gs[e] = 1.f + (a.gbst ? a.gbst[(size_t)n * a.gbst_pitch + c0 + e] : 0.f);
-    bs[e] = a.gbst ? a.gbst[(size_t)n * a.gbst_pitch + a.C + c0 + e] : 0.f;
-    if (MODE == 1) {
-      const float* sm = a.sums + ((size_t)n * a.C + c0 + e) * 4;
-      s1[e] = sm[0] * invHW; s2[e] = sm[1] * invHW;
-    }
+    const int k = cc * CE + e;
+    mean[e] = cst[0][k]; rstd[e] = cst[1][k]; gs[e] = cst[2][k]; bs[e] = cst[3][k];
+    s1[e] = cst[4][k]; s2[e] = cst[5][k];
   }
   const size_t img = (size_t)n * a.HW;
   const T* xb = (const T*)a.x + img * a.x_pitch + c0;
