@@ -121,11 +121,12 @@ def test_conv_fwd_dgrad_wgrad(hip_device, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_conv_groups_epilogues(hip_device, dtype):
+@pytest.mark.parametrize("gshape", [(3, 16, 32), (5, 16, 224)])   # the second has a dY pitch > 1024: register-staged wgrad + fused db
+def test_conv_groups_epilogues(hip_device, dtype, gshape):
     dev = hip_device
     ce = chunk_elems(dtype)
     g = torch.Generator().manual_seed(5)
-    G, cin, cout, N, H, W = 3, 16, 32, 2, 6, 5
+    (G, cin, cout), (N, H, W) = gshape, (2, 6, 5)
     x = torch.randn(N, G * cin, H, W, generator=g)
     w = torch.randn(G * cout, cin, 3, 3, generator=g) / 12
     b = torch.randn(G * cout, generator=g)
