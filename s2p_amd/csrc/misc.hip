@@ -253,22 +253,37 @@ extern "C" int s2p_cast(int sd, const void* src, int dd, void* dst, int64_t n, v
 // ---- reflect-pad adjoint ---------------------------------------------------------------------------------
 template <typename T>
 __global__ void reflect_fold_kernel(const T* dxp, int N, int H, int W, int C, int pad, T* dx) {
-  long long total = (long long)N * H * W * C;
-  int Hp = H + 2 * pad, Wp = W + 2 * pad;
+  // one 16-byte channel chunk of one interior pixel per thread: sums the (up to 3 x 3) padded positions that
+  // reflect onto it.  C is the NHWC pitch, a multiple of the chunk size.
+  constexpr int CE = DT<T>::CE;
+  const int cpr = C / CE;
+  const long long total = (long long)N * H * W * cpr;
+  const int Hp = H + 2 * pad, Wp = W + 2 * pad;
   GRID_STRIDE(idx, total) {
-    int c = (int)(idx % C); long long p = idx / C;
-    int x = (int)(p % W); p /= W; int y = (int)(p % H); int n = (int)(p / H);
+    const int ch = (int)(idx % cpr); long long p = idx / cpr;
+    const int x = (int)(p % W); p /= W; const int y = (int)(p % H); const int n = (int)(p / H);
     int ys[3], xs[3], ny = 0, nx = 0;
     ys[ny++] = y + pad; if (y >= 1 && y <= pad) ys[ny++] = pad - y; if (y <= H - 2 && y >= H - 1 - pad) ys[ny++] = 2 * H - 2 - y + pad;
     xs[nx++] = x + pad; if (x >= 1 && x <= pad) xs[nx++] = pad - x; if (x <= W - 2 && x >= W - 1 - pad) xs[nx++] = 2 * W - 2 - x + pad;
-    float s = 0.f;
+    float s[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) s[e] = 0.f;
     for (int a = 0; a < ny; ++a)
-      for (int b = 0; b < nx; ++b) s += to_f32(dxp[(((size_t)n * Hp + ys[a]) * Wp + xs[b]) * C + c]);
-    dx[idx] = from_f32<T>(s);
+      for (int b = 0; b < nx; ++b) {
+        Chunk<T> v; v.raw = *(const u32x4*)(dxp + (((size_t)n * Hp + ys[a]) * Wp + xs[b]) * C + ch * CE);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) s[e] += v.get(e);
+      }
+    Chunk<T> o;
+#pragma unroll
+    for (int e = 0; e < CE; ++e) o.set(e, s[e]);
+    *(u32x4*)(dx + (size_t)idx * CE) = o.raw;
   }
 }
 extern "C" int s2p_reflect_pad_bwd(int dtype, const void* dxp, int N, int H, int W, int C, int pad, void* dx, void* stream) {
-  long long total = (long long)N * H * W * C;
+  const int ce = dtype == S2P_F32 ? 4 : 8;
+  if (C % ce) S2P_FAIL(-1, "s2p_reflect_pad_bwd: C (the NHWC pitch) must be a multiple of %d", ce);
+  long long total = (long long)N * H * W * (C / ce);
   if (dtype == S2P_F32) hipLaunchKernelGGL(reflect_fold_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)dxp, N, H, W, C, pad, (float*)dx);
   else if (dtype == S2P_BF16) hipLaunchKernelGGL(reflect_fold_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dxp, N, H, W, C, pad, (__bf16*)dx);
   else S2P_FAIL(-1, "s2p_reflect_pad_bwd: bad dtype");
