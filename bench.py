@@ -41,8 +41,8 @@ def parse():
     ap.add_argument("--precision", type=str, default="bf16")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=40)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", type=str, default="", help="torch.distributed backend (default nccl = RCCL; gloo for a 1-GPU rehearsal)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use GPU 0")
