@@ -797,6 +797,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
   __syncthreads();                                     // hipcc drains vmcnt before the barrier
   if (a.diag == 3) return;                              // timing ablation: prologue only
   int slab = 0, tap = 0;
+  // S2P_DIAG=8 (diagnostic build of the launch, output invalid): stamp shader clock and 100 MHz wall clock around the
+  // main loop; the host tool derives the in-kernel clock and cycles per K step (tools/clock_halo.py)
+  unsigned long long st_c0 = 0, st_r0 = 0;
+  if (a.diag == 8) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
   for (int kt = 0; kt < nk; ++kt) {
     const int c0 = slab * BK;
     int ntap = tap + 1, nslab_i = slab;
@@ -851,6 +855,15 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
     }
   }
   (void)nk;
+  if (a.diag == 8) {
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0 && g == 0) {
+      unsigned long long* o = (unsigned long long*)a.y + (size_t)blockIdx.x * 2;
+      o[0] = c1 - st_c0; o[1] = r1 - st_r0;
+    }
+    if (acc[0][0][0] == 12345.678f) ((float*)a.y)[7] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1];
+    return;
+  }
   if (a.diag == 4) { if (acc[0][0][0] == 12345.678f) ((float*)a.y)[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1]; return; }
   conv_epilogue<T, BCO, BPIX, TCO, TPIX>(a, acc, smem, rowoff, g, co_base, wco0, wpix0, r, h, tid);
 }
