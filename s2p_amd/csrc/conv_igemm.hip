@@ -666,13 +666,13 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const GatherArgs a) {
 // neighbouring rows and images) is staged ONCE and stays resident in LDS while all taps are swept; only the 16 KiB
 // weight stage is streamed per tap.  Per 3x3 slab: 22 + 9*16 KiB instead of 9*32 KiB (-42 % L2 traffic).
 // Tap validity (zero padding, image/row borders) is a per-pixel bit mask; an invalid (pixel, tap) reads a zero row.
-template <int NPOS_CAP, bool DBUF>
+template <int NPOS_CAP, bool DBUF, int TS = 0>      // TS: static tap count (9 = 3x3, taps unrolled) or 0 = run-time taps
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
   typedef __bf16 T;
   constexpr int BCO = 128, BPIX = 128, WPIX = 2, TCO = 2, TPIX = 2;
   constexpr int BK = 64, RS = 128;
   constexpr int WSTAGE = BCO * RS;                     // 16 KiB weight stage
-  constexpr int HALO = NPOS_CAP * RS;
+  constexpr int HALO = (NPOS_CAP + 1) * RS;            // + one all-zero row per halo buffer (target of invalid taps, TS variant)
   constexpr int ERS = BCO * 2 + 16;
   constexpr int EPI = BPIX * ERS;
   constexpr int NHB = DBUF ? 2 : 1;                    // halo buffers (double-buffered when two workgroups still fit a CU)
@@ -703,6 +703,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
     rowoff[tid] = m < a.M ? m : -1;                   // same grid: output pixel index == GEMM pixel index
   }
   if (tid < 64) *(u32x4*)(zrow + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
+  if (tid < 8 * NHB) *(u32x4*)(hbase + (tid >> 3) * HALO + NPOS_CAP * RS + (tid & 7) * 16) = (u32x4){0u, 0u, 0u, 0u};
 
   const unsigned OOB = 0x80000000u;
   const T* xg = (const T*)a.x + (size_t)g * a.x_gstride;
@@ -789,6 +790,82 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
   // one linear pipeline over (slab, tap): weights are always one step ahead; the next slab's halo is prefetched
   // into the other halo buffer during the current slab (DBUF) or loaded behind a barrier at the slab boundary.
   if (a.diag == 5) return;                              // timing ablation: index set-up only
+  if constexpr (TS > 0) {
+    // Static-tap form (3x3): everything that depends only on (lane, tap) is computed ONCE -- the halo row a lane reads
+    // for tap t (or the zero row when the tap falls outside the image), with the row's XOR swizzle folded into the low
+    // bits, so a fragment address in the loop is  halo_base + (pk[t][j] ^ chunk_offset)  -- and the taps are unrolled:
+    // no tap decode, validity test, address select or kernarg load per K step (they cost ~470 of ~1500 cycles a step).
+    int pk[TS][TPIX];
+    int wtv[TS];
+#pragma unroll
+    for (int t = 0; t < TS; ++t) {
+      const int ti = a.tap[t];
+      wtv[t] = ti >> 16;
+      const int toff = (int)(signed char)(ti & 0xff) * a.Wi + (int)(signed char)((ti >> 8) & 0xff);
+#pragma unroll
+      for (int j = 0; j < TPIX; ++j) {
+        const int hp = wpix0 + 32 * j + r + a.halo_lo + toff;
+        const bool ok = (vmask[j] >> t) & 1ull;
+        pk[t][j] = ok ? hp * RS + ((hp >> 1) & 7) * 16 : NPOS_CAP * RS;
+      }
+    }
+    const int ch16[4] = {(0 + h) * 16, (2 + h) * 16, (4 + h) * 16, (6 + h) * 16};
+    issue_halo(0, 0);
+    issue_w(0, wtv[0] << 16, 0);
+    __syncthreads();
+    if (a.diag == 3) return;
+    unsigned long long st_c0 = 0, st_r0 = 0;
+    if (a.diag == 8) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+    int kt = 0;
+    for (int slab = 0; slab < nslab; ++slab) {
+      const char* hb = hbase + (DBUF ? (slab & 1) * HALO : 0);
+      const bool more_slabs = slab + 1 < nslab;
+#pragma unroll
+      for (int t = 0; t < TS; ++t, ++kt) {
+        if (a.diag != 1) {
+          if (t + 1 < TS) issue_w((kt + 1) & 1, wtv[t + 1] << 16, slab * BK);
+          else if (more_slabs) issue_w((kt + 1) & 1, wtv[0] << 16, (slab + 1) * BK);
+          if (DBUF && t == 0 && more_slabs) issue_halo((slab + 1) & 1, (slab + 1) * BK);
+        }
+        const char* wrow = wbase + (kt & 1) * WSTAGE + (wco0 + r) * RS;
+        if (a.diag != 2) {
+          bf16x8 af[4][TCO], bf[4][TPIX];
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+            for (int i = 0; i < TCO; ++i) af[s4][i] = *(const bf16x8*)(wrow + i * 32 * RS + (((2 * s4 + h) ^ swr) * 16));
+#pragma unroll
+            for (int j = 0; j < TPIX; ++j) bf[s4][j] = *(const bf16x8*)(hb + (pk[t][j] ^ ch16[s4]));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int i = 0; i < TCO; ++i)
+#pragma unroll
+              for (int j = 0; j < TPIX; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s4][i], bf[s4][j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+      }
+      if (!DBUF && more_slabs) {                        // single halo buffer: reload it now that nobody reads it
+        issue_halo(0, (slab + 1) * BK);
+        __syncthreads();
+      }
+    }
+    if (a.diag == 8) {
+      const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+      if (tid == 0 && g == 0) {
+        unsigned long long* o = (unsigned long long*)a.y + (size_t)blockIdx.x * 2;
+        o[0] = c1 - st_c0; o[1] = r1 - st_r0;
+      }
+      if (acc[0][0][0] == 12345.678f) ((float*)a.y)[7] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1];
+      return;
+    }
+    if (a.diag == 4) { if (acc[0][0][0] == 12345.678f) ((float*)a.y)[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1]; return; }
+    conv_epilogue<T, BCO, BPIX, TCO, TPIX>(a, acc, smem, rowoff, g, co_base, wco0, wpix0, r, h, tid);
+    return;
+  }
   // tap words travel one step ahead of their use (a kernarg scalar load waited for on the spot stalls every step)
   int tw_cur = a.tap[0];
   int tw_next = a.tap[a.T > 1 ? 1 : 0];
@@ -889,6 +966,11 @@ static int launch_fast(GatherArgs& a, int groups, hipStream_t st) {
       a.halo_lo = lo; a.halo_hi = hi;
       const int npos = BPIX + lo + hi;
       static const int extra_lds = getenv("S2P_HALO_EXTRA_LDS") ? atoi(getenv("S2P_HALO_EXTRA_LDS")) : 0;   // occupancy experiment
+      static const int no_ts = getenv("S2P_NO_STATIC_TAPS") ? 1 : 0;
+      if (a.T == 9 && !no_ts) {
+        if (npos <= 176) { hipLaunchKernelGGL((conv_halo_kernel<176, true, 9>), grid, dim3(256), extra_lds, st, a); S2P_CHECK_LAUNCH("conv_halo_kernel"); return 0; }
+        if (npos <= 320) { hipLaunchKernelGGL((conv_halo_kernel<320, false, 9>), grid, dim3(256), 0, st, a); S2P_CHECK_LAUNCH("conv_halo_kernel"); return 0; }
+      }
       if (npos <= 176) { hipLaunchKernelGGL((conv_halo_kernel<176, true>), grid, dim3(256), extra_lds, st, a); S2P_CHECK_LAUNCH("conv_halo_kernel"); return 0; }
       if (npos <= 320) { hipLaunchKernelGGL((conv_halo_kernel<320, false>), grid, dim3(256), 0, st, a); S2P_CHECK_LAUNCH("conv_halo_kernel"); return 0; }
     }
