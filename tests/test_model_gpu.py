@@ -39,7 +39,7 @@ def grad_errors(named_hip, ref64, ref32=None, floor_frac=1e-3):
 def check_grads(errs, gtol, frac_exact=None, exact_tol=1e-4):
     """ReLU / LeakyReLU kinks make the gradient a discontinuous function of the activations: one element whose
     pre-activation rounds to the other side of 0 (fp32 vs fp64, or bf16 vs fp32) changes every upstream gradient by
-    an isolated 3x3 footprint (measured: tools/diag4.py), i.e. ~1e-3 relative L2 in fp32.  So: every parameter
+    an isolated 3x3 footprint (measured: tests/tools/diag4.py), i.e. ~1e-3 relative L2 in fp32.  So: every parameter
     within `gtol`, and (fp32) a fraction of the parameters -- those with no flipped element upstream -- exact."""
     for k, (e, _) in errs.items():
         assert e < gtol, (k, e, errs[k])

@@ -89,7 +89,7 @@ def test_oracle_backward_matches_the_real_reference():
 @pytest.mark.gpu
 # fp32 is exact to 1e-5 in practice (tolerance 1e-3).  bf16 (bf16 operands and bf16 inter-layer gradients, fp32 accumulate)
 # drifts by ~1.2 % relative L2 per layer walked backwards -- 0.3 % at the last layer, 7 % at the first / at dz
-# (tools/diag_slac_bwd.py) -- hence the 0.1 bound; the reference itself trains these stacks in fp32.
+# (tests/tools/diag_slac_bwd.py) -- hence the 0.1 bound; the reference itself trains these stacks in fp32.
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 1e-1)])
 def test_hip_slac_backward_matches_the_real_reference(hip_device, dtype, tol):
     from s2p_amd.slac import Decoder, Encoder

@@ -1,6 +1,6 @@
 """N2 measurement: ensemble dynamics forward + post-processing, HIP vs the CPU oracle restatement (16 host threads)."""
 import os, sys, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in ("", "oracle"): sys.path.insert(0, os.path.join(R, p))
 import torch
 import ensemble_oracle as EO

@@ -1,6 +1,6 @@
 """N3 measurement: SLAC encoder / decoder forward and forward+backward on HIP vs the CPU oracle restatement (16 host threads)."""
 import os, sys, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in ("", "oracle"): sys.path.insert(0, os.path.join(R, p))
 import torch
 import slac_oracle as SO

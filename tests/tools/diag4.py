@@ -1,5 +1,5 @@
 import sys, os
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in ("", "tests", "oracle"): sys.path.insert(0, os.path.join(R, p))
 import torch, torch.nn.functional as F
 import s2p_oracle as O

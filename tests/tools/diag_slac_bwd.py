@@ -1,6 +1,6 @@
 """bf16 / fp32 gradient error of the SLAC stacks vs the reference fixture, per parameter (diagnostic)."""
 import os, sys
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "oracle"))
 import numpy as np, torch
 import slac_oracle as SO
