@@ -12,6 +12,7 @@
 // padded to 80 B (conflict-free ds_read_b128); global->register->LDS staging, double buffered, one barrier
 // per K step; epilogue goes through LDS so every global store is a full 16-B chunk along the channel axis.
 #include "s2p_common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 #define MAX_TAPS 64
@@ -39,6 +40,11 @@ struct GatherArgs {
   int nphase;
   struct Phase { int Qh, Qw, M, oy0, ox0, T, Ktot, npix_tiles; int tap[PHASE_TAPS]; } ph[MAX_PHASES];
 };
+
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
+}
 
 template <typename T> struct Mma;
 template <> struct Mma<__bf16> { static constexpr int BK = 32; };
@@ -666,7 +672,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const GatherArgs a) {
 // neighbouring rows and images) is staged ONCE and stays resident in LDS while all taps are swept; only the 16 KiB
 // weight stage is streamed per tap.  Per 3x3 slab: 22 + 9*16 KiB instead of 9*32 KiB (-42 % L2 traffic).
 // Tap validity (zero padding, image/row borders) is a per-pixel bit mask; an invalid (pixel, tap) reads a zero row.
-template <int NPOS_CAP, bool DBUF, int TS = 0>      // TS: static tap count (9 = 3x3, taps unrolled) or 0 = run-time taps
+template <int NPOS_CAP, bool DBUF, int TS = 0, bool PIPE = false>   // TS: static tap count (9 = 3x3, taps unrolled) or 0 = run-time taps
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
   typedef __bf16 T;
   constexpr int BCO = 128, BPIX = 128, WPIX = 2, TCO = 2, TPIX = 2;
@@ -790,7 +796,149 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
   // one linear pipeline over (slab, tap): weights are always one step ahead; the next slab's halo is prefetched
   // into the other halo buffer during the current slab (DBUF) or loaded behind a barrier at the slab boundary.
   if (a.diag == 5) return;                              // timing ablation: index set-up only
-  if constexpr (TS > 0) {
+  if constexpr (TS > 0 && PIPE && DBUF) {
+    // Software-pipelined static-tap form.  The weight stage is split into BK=32 HALF-stages (4 x 8 KiB in the same
+    // 32 KiB as two full stages): the DMA of half-step h+3 is issued (inline asm, so the waits can be counted) while
+    // half-step h computes, the fragments of half-step h+1 are read from LDS into a second register set under the MFMAs
+    // of half-step h, and the only wait before the raw s_barrier is vmcnt(N) for the half-stage needed two steps later.
+    constexpr int WHALF = BCO * 64;                     // 8 KiB: 128 rows x 64 B, chunk' = chunk ^ ((row >> 2) & 3)
+    int pk[TS][TPIX];
+    int wtv[TS];
+#pragma unroll
+    for (int t = 0; t < TS; ++t) {
+      const int ti = a.tap[t];
+      wtv[t] = ti >> 16;
+      const int toff = (int)(signed char)(ti & 0xff) * a.Wi + (int)(signed char)((ti >> 8) & 0xff);
+#pragma unroll
+      for (int j = 0; j < TPIX; ++j) {
+        const int hp = wpix0 + 32 * j + r + a.halo_lo + toff;
+        const bool ok = (vmask[j] >> t) & 1ull;
+        pk[t][j] = ok ? hp * RS + ((hp >> 1) & 7) * 16 : NPOS_CAP * RS;
+      }
+    }
+    const int ch16[4] = {(0 + h) * 16, (2 + h) * 16, (4 + h) * 16, (6 + h) * 16};
+    const i32x4 wrs = s2p_make_rsrc(wg, a.w_bytes);
+    const i32x4 xrs = s2p_make_rsrc(xg, a.x_bytes - (unsigned)g * (unsigned)a.x_gstride * 2u);
+    const unsigned wb_lds = __builtin_amdgcn_readfirstlane(s2p_lds_addr(wbase));
+    const unsigned hb_lds = __builtin_amdgcn_readfirstlane(s2p_lds_addr(hbase));
+    // weight half-stage DMA: piece p = 16 rows x 64 B; wave w issues pieces w and w + 4
+    unsigned wv[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int row = 16 * (wave + 4 * q) + (lane >> 2);
+      const int c = (lane & 3) ^ ((row >> 2) & 3);
+      const int co = co_base + row;
+      wv[q] = co < a.Cout ? (unsigned)(co * a.w_row * 2 + c * 16) : OOB;
+    }
+    auto issue_wh = [&](int hs, int wt, int kofs) {
+      const unsigned dst = wb_lds + (unsigned)((hs & 3) * WHALF + wave * 1024);
+      const unsigned woff = (unsigned)((wt * a.Cin + kofs) * 2);
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        s2p_dma16(wrs, dst + q * 4096, (int)(wv[q] == OOB ? OOB : wv[q] + woff));
+    };
+    // halo DMA: every wave issues exactly NHP pieces (the last ones repeat its last real piece), so vmcnt counts are fixed
+    constexpr int NHPc = (NPOS_CAP / 8 + 3) / 4;
+    const int last_piece = (npos + 7) / 8 - 1;
+    unsigned hv[NHPc]; int hpc[NHPc];
+#pragma unroll
+    for (int i = 0; i < NHPc; ++i) {
+      int pc8 = 4 * i + wave; if (pc8 > last_piece) pc8 = last_piece - ((last_piece - wave) & 3);   // this wave's last real piece
+      if (pc8 < 0) pc8 = wave <= last_piece ? wave : 0;
+      hpc[i] = pc8;
+      const int pos = pc8 * 8 + lrow;
+      const int c = pc ^ ((pos >> 1) & 7);
+      const long long gpix = (long long)pix_base - a.halo_lo + pos;
+      hv[i] = (pos < npos && gpix >= 0 && gpix < a.M) ? (unsigned)(gpix * a.x_pitch * 2 + c * 16) : OOB;
+    }
+    auto issue_halo_p = [&](int hbuf, int c0) {
+      const unsigned dst = hb_lds + (unsigned)(hbuf * HALO);
+#pragma unroll
+      for (int i = 0; i < NHPc; ++i)
+        s2p_dma16(xrs, dst + (unsigned)(hpc[i] * 1024), (int)(hv[i] == OOB ? OOB : hv[i] + (unsigned)(c0 * 2)));
+    };
+    const int arow[TCO] = {(wco0 + r) * 64, (wco0 + 32 + r) * 64};
+    const int asw = (r >> 2) & 3;
+    bf16x8 FA[2][2][TCO], FB[2][2][TPIX];
+    auto read_frags = [&](auto bufc, int hs, auto tc, auto halfc, const char* hbp) {
+      constexpr int buf = decltype(bufc)::value, t = decltype(tc)::value, half = decltype(halfc)::value;
+      const char* wbp = wbase + (hs & 3) * WHALF;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+        for (int i = 0; i < TCO; ++i) FA[buf][s2][i] = *(const bf16x8*)(wbp + arow[i] + (((2 * s2 + h) ^ asw) * 16));
+#pragma unroll
+        for (int j = 0; j < TPIX; ++j) FB[buf][s2][j] = *(const bf16x8*)(hbp + (pk[t][j] ^ ch16[2 * half + s2]));
+      }
+    };
+    const int nhs = nslab * TS * 2;
+    issue_halo_p(0, 0);
+    issue_wh(0, wtv[0], 0);
+    issue_wh(1, wtv[0], 32);
+    if (nhs > 2) { issue_wh(2, wtv[1], 0); S2P_WAIT_VMCNT(2); } else { S2P_WAIT_VMCNT(0); }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (a.diag == 3) return;
+    unsigned long long st_c0 = 0, st_r0 = 0;
+    if (a.diag == 8) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+    read_frags(std::integral_constant<int, 0>{}, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, hbase);
+    int hs = 0;
+    for (int slab = 0; slab < nslab; ++slab) {
+      const char* hb = hbase + (slab & 1) * HALO;
+      const char* hb_next = hbase + ((slab + 1) & 1) * HALO;
+      const bool more_slabs = slab + 1 < nslab;
+      static_for<0, 2 * TS>([&](auto uc) {               // u = 2 * tap + half (compile time: register sets and taps are static)
+        constexpr int u = decltype(uc)::value;
+        // (1) DMA of half-step hs + 3
+        constexpr int u3 = u + 3;
+        bool issued = false, halo_issued = false;
+        if constexpr (u3 < 2 * TS) {
+          issue_wh(hs + 3, wtv[u3 >> 1], slab * BK + (u3 & 1) * 32); issued = true;
+        } else {
+          if (more_slabs) { issue_wh(hs + 3, wtv[(u3 - 2 * TS) >> 1], (slab + 1) * BK + ((u3 - 2 * TS) & 1) * 32); issued = true; }
+        }
+        if constexpr (u == 0) {
+          if (more_slabs) { issue_halo_p((slab + 1) & 1, (slab + 1) * BK); halo_issued = true; }
+        }
+        // (2) fragments of half-step hs + 1 into the other register set
+        if constexpr (u + 1 < 2 * TS) {
+          read_frags(std::integral_constant<int, (u + 1) & 1>{}, hs + 1, std::integral_constant<int, (u + 1) / 2>{},
+                     std::integral_constant<int, (u + 1) & 1>{}, hb);
+        } else {
+          if (more_slabs)
+            read_frags(std::integral_constant<int, 0>{}, hs + 1, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, hb_next);
+        }
+        // (3) the MFMAs of half-step hs from the current register set
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int i = 0; i < TCO; ++i)
+#pragma unroll
+            for (int j = 0; j < TPIX; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[u & 1][s2][i], FB[u & 1][s2][j], acc[i][j], 0, 0, 0);
+        // (4) half-stage hs + 2 must have landed for every wave before the next step reads it
+        if (issued) { if (halo_issued) S2P_WAIT_VMCNT(2 + NHPc); else S2P_WAIT_VMCNT(2); }
+        else S2P_WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        ++hs;
+      });
+    }
+    if (a.diag == 8) {
+      const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+      if (tid == 0 && g == 0) {
+        unsigned long long* o = (unsigned long long*)a.y + (size_t)blockIdx.x * 2;
+        o[0] = c1 - st_c0; o[1] = r1 - st_r0;
+      }
+      if (acc[0][0][0] == 12345.678f) ((float*)a.y)[7] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1];
+      return;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (a.diag == 4) { if (acc[0][0][0] == 12345.678f) ((float*)a.y)[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1]; return; }
+    conv_epilogue<T, BCO, BPIX, TCO, TPIX>(a, acc, smem, rowoff, g, co_base, wco0, wpix0, r, h, tid);
+    return;
+  } else if constexpr (TS > 0) {
     // Static-tap form (3x3): everything that depends only on (lane, tap) is computed ONCE -- the halo row a lane reads
     // for tap t (or the zero row when the tap falls outside the image), with the row's XOR swizzle folded into the low
     // bits, so a fragment address in the loop is  halo_base + (pk[t][j] ^ chunk_offset)  -- and the taps are unrolled:
@@ -967,6 +1115,10 @@ static int launch_fast(GatherArgs& a, int groups, hipStream_t st) {
       const int npos = BPIX + lo + hi;
       static const int extra_lds = getenv("S2P_HALO_EXTRA_LDS") ? atoi(getenv("S2P_HALO_EXTRA_LDS")) : 0;   // occupancy experiment
       static const int no_ts = getenv("S2P_NO_STATIC_TAPS") ? 1 : 0;
+      static const int pipe = getenv("S2P_NO_HALO_PIPE") ? 0 : 1;         // A/B switch: software-pipelined variant (default on)
+      if (a.T == 9 && !no_ts && pipe && npos <= 176 && a.Cin % 64 == 0) {
+        hipLaunchKernelGGL((conv_halo_kernel<176, true, 9, true>), grid, dim3(256), extra_lds, st, a); S2P_CHECK_LAUNCH("conv_halo_kernel"); return 0;
+      }
       if (a.T == 9 && !no_ts) {
         if (npos <= 176) { hipLaunchKernelGGL((conv_halo_kernel<176, true, 9>), grid, dim3(256), extra_lds, st, a); S2P_CHECK_LAUNCH("conv_halo_kernel"); return 0; }
         if (npos <= 320) { hipLaunchKernelGGL((conv_halo_kernel<320, false, 9>), grid, dim3(256), 0, st, a); S2P_CHECK_LAUNCH("conv_halo_kernel"); return 0; }
