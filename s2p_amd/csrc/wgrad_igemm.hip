@@ -118,14 +118,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int wa0 = (wave >> 1) * (TT * 32), wb0 = (wave & 1) * (TT * 32);
-  // fused bias gradient (bf16): workgroups of B-tile 0 add  db[a] += sum_m A[m][a]  with one extra MFMA per A fragment
-  // against a ones fragment, so dY is not read again by a separate channel-sum pass
-  f32x16 accb[TT];
-#pragma unroll
-  for (int i = 0; i < TT; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) accb[i][e] = 0.f;
-  const bool do_bias = sizeof(T) == 2 && a.db != nullptr && b_tile == 0 && wb0 == 0;          // wave-uniform
 
   load_global();
   store_lds(0);
@@ -167,13 +159,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
           for (int j = 0; j < TT; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-        if (do_bias) {
-          typedef __attribute__((ext_vector_type(8))) short s16x8;
-          const s16x8 ones_s = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};   // bf16 1.0
-          const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
-#pragma unroll
-          for (int i = 0; i < TT; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], ones, accb[i], 0, 0, 0);
-        }
       }
     } else {
       const int r = lane & 31, h = lane >> 5;
@@ -204,16 +189,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
       for (int e = 0; e < 16; ++e) {
         int arow = a_tile * BT + wa0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (arow < a.Ca_real) atomicAdd(dWg + (size_t)arow * a.dw_row + col, acc[i][j][e]);
-      }
-  }
-  if (do_bias && r == 0) {                                // every column of accb holds the same row sums
-    float* dbg = a.db + (size_t)g * a.Ca_real;
-#pragma unroll
-    for (int i = 0; i < TT; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        int arow = a_tile * BT + wa0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (arow < a.Ca_real) atomicAdd(dbg + arow, accb[i][e]);
       }
   }
 }
@@ -491,10 +466,7 @@ extern "C" int s2p_conv2d_wgrad(const s2p_conv_desc* d, const void* x, const voi
     dim3 grid1(8 * tiles * cdiv(units, 8));
     hipLaunchKernelGGL(wgrad_dma_kernel<32>, grid1, dim3(256), 0, st, a);
   } else {
-    static const int no_fused_db = getenv("S2P_NO_FUSED_DB") ? 1 : 0;
-    if (db && d->dtype == S2P_BF16 && !no_fused_db) {
-      a.db = db;                                  // bf16: bias gradient fused into the wgrad pass (ones-fragment MFMA)
-    } else if (db) {
+    if (db) {
       int rc = s2p_channel_sum(d->dtype, dy, (int64_t)d->N * d->Ho * d->Wo, cout_real * d->groups, d->y_pitch, db, stream);
       if (rc) return rc;
     }
