@@ -201,13 +201,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 // ds_read_b64_tr_b16 conflict-free (one image serves the 32x32x16 A and B fragments).
 // Workgroups of B-tile 0 also accumulate the bias gradient  db[a] += sum_m A[m][a]  with one extra MFMA against a
 // ones fragment per A fragment, so dY is not read a second time by a separate reduction kernel.
-template <int BKP>
+template <int BKP, int NST = 3, bool FUSE_DB = true>
 __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
   typedef __bf16 T;
   constexpr int BT = 128, RS = 256, TT = 2;
   constexpr int NP = BKP / 16;                        // DMA pieces (4 rows) per wave per operand per step
   constexpr int TILE = BKP * RS;                      // 8 KiB per operand
-  constexpr int NST = 3;                              // pipeline stages: two K steps of LDS-DMA in flight behind the MFMAs
+  // NST pipeline stages: 3 = two K steps of LDS-DMA in flight behind the MFMAs; 2 = one (32 KiB LDS: 4 workgroups per CU)
   __shared__ __attribute__((aligned(1024))) char smem[NST * 2 * TILE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   }
   const int wa0 = (wave >> 1) * (TT * 32), wb0 = (wave & 1) * (TT * 32);
-  const bool do_bias = a.db != nullptr && b_tile == 0 && wb0 == 0;          // wave-uniform
+  const bool do_bias = FUSE_DB && a.db != nullptr && b_tile == 0 && wb0 == 0;          // wave-uniform
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   const s16x8 ones_s = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};   // bf16 1.0
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
@@ -304,15 +304,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
   // 3-stage pipeline: while step kt computes, the DMAs of steps kt+1 and kt+2 are in flight.  The only waits are a
   // counted vmcnt (all but the newest stage's 2*NP DMA instructions) and a raw s_barrier -- never vmcnt(0) in the loop.
   issue(0);
-  if (nsteps > 1) issue(1);
-  if (nsteps > 1) S2P_WAIT_VMCNT(2 * NP);
+  if (NST == 3 && nsteps > 1) issue(1);
+  if (NST == 3 && nsteps > 1) S2P_WAIT_VMCNT(2 * NP);
   else S2P_WAIT_VMCNT(0);
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   int stage = 0;
   for (int kt = 0; kt < nsteps; ++kt) {
-    int st2 = stage + 2; if (st2 >= NST) st2 -= NST;
-    if (kt + 2 < nsteps && a.diag != 1) issue(st2);
+    int st2 = stage + (NST - 1); if (st2 >= NST) st2 -= NST;
+    if (kt + (NST - 1) < nsteps && a.diag != 1) issue(st2);
     const char* At = smem + stage * 2 * TILE;
     const char* Bt = At + TILE;
     if (a.diag != 2)
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
       }
     }
     // stage kt+1 must have landed (for every wave) before anyone reads it; stage kt+2 may stay in flight
-    if (kt + 2 < nsteps) S2P_WAIT_VMCNT(2 * NP);
+    if (NST == 3 && kt + 2 < nsteps) S2P_WAIT_VMCNT(2 * NP);
     else S2P_WAIT_VMCNT(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -444,9 +444,31 @@ extern "C" int s2p_conv2d_wgrad(const s2p_conv_desc* d, const void* x, const voi
   hipStream_t st = (hipStream_t)stream;
   const long long abytes = (long long)d->N * a.Qh * a.Qw * a.a_pitch * 2, bbytes = (long long)d->N * a.Hi * a.Wi * a.b_pitch * 2;
   static const int no_dma = getenv("S2P_NO_LDS_DMA") ? 1 : 0;
-  // LDS-DMA staging pays for dense operands; for large-pitch (grouped / channel-sliced) operands the register-staged
-  // kernel measured faster on MI355X (658 vs 930 us on the 12-group gamma/beta wgrad), so it keeps that path.
   const bool dense = a.a_pitch <= 1024 && a.b_pitch <= 1024;
+  // Large-pitch (grouped / channel-sliced) operands: these launches are L2-latency-bound and live on occupancy, so they
+  // take the 2-stage DMA kernel without the fused bias accumulators (126 VGPRs, 32 KiB LDS: 4 workgroups per CU; the
+  // 3-stage + fused-bias form is 146 VGPRs / 48 KiB = 3 per CU and measured 930 us on the 12-group gamma/beta wgrad,
+  // the register-staged kernel 670 us, this form 521 us).  The bias gradient is a separate channel-sum pass here.
+  static const int wide_dma = getenv("S2P_NO_WGRAD_WIDE_DMA") ? 0 : 1;
+  if (d->dtype == S2P_BF16 && !no_dma && !dense && wide_dma && abytes < (1ll << 31) && bbytes < (1ll << 31)) {
+    a.a_bytes = (unsigned)abytes; a.b_bytes = (unsigned)bbytes;
+    a.db = nullptr;
+    if (db) { int rc = s2p_channel_sum(d->dtype, dy, (int64_t)d->N * d->Ho * d->Wo, cout_real * d->groups, d->y_pitch, db, stream); if (rc) return rc; }
+    const int tiles = a.na_tiles * a.nb_tiles;
+    const int total = cdiv(a.M, 32);
+    const int target = 384;
+    int U = 8 * (cdiv(target, tiles * 8) > 1 ? cdiv(target, tiles * 8) : 1);
+    int sk = cdiv(U, d->groups);
+    if (sk > total) sk = total;
+    if (sk < 1) sk = 1;
+    a.steps_per_split = cdiv(total, sk); a.splitk = cdiv(total, a.steps_per_split);
+    a.groups = d->groups;
+    const int units = a.groups * a.splitk;
+    dim3 grid1(8 * tiles * cdiv(units, 8));
+    hipLaunchKernelGGL((wgrad_dma_kernel<32, 2, false>), grid1, dim3(256), 0, st, a);
+    S2P_CHECK_LAUNCH("wgrad_dma_kernel");
+    return 0;
+  }
   if (d->dtype == S2P_BF16 && !no_dma && dense && abytes < (1ll << 31) && bbytes < (1ll << 31)) {
     a.a_bytes = (unsigned)abytes; a.b_bytes = (unsigned)bbytes;
     static const int diag = getenv("S2P_DIAG") ? atoi(getenv("S2P_DIAG")) : 0;
