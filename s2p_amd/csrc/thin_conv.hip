@@ -277,17 +277,21 @@ __device__ __forceinline__ void load_halo_simple(const TileArgs& a, char* xt, in
   }
 }
 
+// KS / CS: compile-time kernel size / Cin (0 = run-time): the 49 x 2 (tap, 32-channel) steps of the 7x7 64->3 conv are
+// then straight-line code whose LDS reads the compiler can hoist over the MFMAs
+template <int KS, int CS>
 __global__ __launch_bounds__(256) void thin_tiled_fwd_kernel(const TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int T = a.K * a.K, HW_ = TW + a.K - 1, HH = TH + a.K - 1;
-  const int xs = a.Cin * 2 + 16;                         // halo position stride (padded: conflict-free b128 reads)
+  const int aK = KS > 0 ? KS : a.K, aCin = CS > 0 ? CS : a.Cin;
+  const int T = aK * aK, HW_ = TW + aK - 1, HH = TH + aK - 1;
+  const int xs = aCin * 2 + 16;                         // halo position stride (padded: conflict-free b128 reads)
   char* xt = smem;
   char* wt = xt + HW_ * HH * xs;                         // [Cout][T][Cin] bf16
-  char* ot = wt + a.Cout * T * a.Cin * 2;                // [128 pixels][8] bf16 output staging
+  char* ot = wt + a.Cout * T * aCin * 2;                // [128 pixels][8] bf16 output staging
   const int tile = blockIdx.x;
   const int n = tile / (a.tiles_x * a.tiles_y), tr = tile - n * a.tiles_x * a.tiles_y;
   const int oy0 = (tr / a.tiles_x) * TH, ox0 = (tr % a.tiles_x) * TW;
-  const int wbytes = a.Cout * T * a.Cin * 2;
+  const int wbytes = a.Cout * T * aCin * 2;
   for (int i = threadIdx.x * 16; i < wbytes; i += 256 * 16) *(u32x4*)(wt + i) = *(const u32x4*)((const char*)a.w + i);
   for (int i = threadIdx.x * 16; i < TW * TH * 16; i += 256 * 16) *(u32x4*)(ot + i) = (u32x4){0u, 0u, 0u, 0u};
   load_halo<10>(a, xt, xs, n, oy0, ox0, HW_, HH);
@@ -297,13 +301,16 @@ __global__ __launch_bounds__(256) void thin_tiled_fwd_kernel(const TileArgs a) {
   const int l15 = lane & 15, kg = lane >> 4;             // A: pixel row l15, k group kg ; B: column (co) l15
   f32x4_t acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   const bf16x8 zero8 = {};
-  const int nck = a.Cin / 32;
-  for (int ky = 0; ky < a.K; ++ky)
-    for (int kx = 0; kx < a.K; ++kx) {
-      const int t = ky * a.K + kx;
+  const int nck = aCin / 32;
+#pragma unroll
+  for (int ky = 0; ky < aK; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < aK; ++kx) {
+      const int t = ky * aK + kx;
+#pragma unroll
       for (int ck = 0; ck < nck; ++ck) {
         bf16x8 bfrag = zero8;
-        if (l15 < a.Cout) bfrag = *(const bf16x8*)(wt + ((l15 * T + t) * a.Cin + ck * 32 + kg * 8) * 2);
+        if (l15 < a.Cout) bfrag = *(const bf16x8*)(wt + ((l15 * T + t) * aCin + ck * 32 + kg * 8) * 2);
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
           const int ry = wave * 2 + rr;
@@ -333,17 +340,18 @@ __global__ __launch_bounds__(256) void thin_tiled_fwd_kernel(const TileArgs a) {
 }
 
 // 512 threads (8 waves); persistent over tiles; each wave owns (tap, 16-channel group) pairs w, w+8, ...
-template <int MAXP>
+template <int MAXP, int KS = 0, int CS = 0>          // KS / CS: compile-time kernel size / Cin (0 = run-time)
 __global__ __launch_bounds__(512) void thin_tiled_wgrad_kernel(const TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int T = a.K * a.K, HW_ = TW + a.K - 1, HH = TH + a.K - 1;
-  const int xs = a.Cin * 2 + 16;
+  const int aK = KS > 0 ? KS : a.K, aCin = CS > 0 ? CS : a.Cin;
+  const int T = aK * aK, HW_ = TW + aK - 1, HH = TH + aK - 1;
+  const int xs = aCin * 2 + 16;
   char* xt = smem;
   char* dyt = xt + HW_ * HH * xs;                        // [4 co][128 pixels] bf16, transposed dY tile
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, kg = lane >> 4;
   const int q = (lane >> 2) & 3, p = lane & 3;           // transposed-read lane roles inside the 16-lane group
-  const int ncg = a.Cin / 16, npairs = T * ncg;
+  const int ncg = aCin / 16, npairs = T * ncg;
   f32x4_t acc[MAXP];
 #pragma unroll
   for (int i = 0; i < MAXP; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -375,7 +383,7 @@ __global__ __launch_bounds__(512) void thin_tiled_wgrad_kernel(const TileArgs a)
         const int pr = wave + 8 * i;
         if (pr < npairs) {                                // wave-uniform
           const int t = pr / ncg, cg = pr - t * ncg;
-          const int ky = t / a.K, kx = t - ky * a.K;
+          const int ky = t / aK, kx = t - ky * aK;
           const char* base = xt + ((ry + ky) * HW_ + px0 + kx + q) * xs + (cg * 16 + 4 * p) * 2;
           s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
           s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * xs));
@@ -425,7 +433,9 @@ int s2p_thin_tiled_fwd(const s2p_conv_desc* d, const void* x, const void* w, con
   a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = bias; a.y = (__bf16*)y; a.act = act; a.slope = slope;
   const int HW_ = TW + d->KH - 1, HH = TH + d->KH - 1;
   const size_t lds = (size_t)HW_ * HH * (d->Cin * 2 + 16) + (size_t)d->Cout * d->KH * d->KW * d->Cin * 2 + TW * TH * 16;
-  hipLaunchKernelGGL(thin_tiled_fwd_kernel, dim3(a.ntiles), dim3(256), lds, st, a);
+  static const int no_static = getenv("S2P_NO_THIN_STATIC") ? 1 : 0;
+  if (d->KH == 7 && d->Cin == 64 && !no_static) hipLaunchKernelGGL((thin_tiled_fwd_kernel<7, 64>), dim3(a.ntiles), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((thin_tiled_fwd_kernel<0, 0>), dim3(a.ntiles), dim3(256), lds, st, a);
   S2P_CHECK_LAUNCH("thin_tiled_fwd_kernel");
   return 0;
 }
@@ -438,7 +448,9 @@ int s2p_thin_tiled_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, 
   const size_t lds = (size_t)HW_ * HH * (d->Cin * 2 + 16) + 4 * TW * TH * 2;
   const int pairs = d->KH * d->KW * (d->Cin / 16);
   int blocks = a.ntiles < 512 ? a.ntiles : 512;
-  if (pairs <= 8 * 13) hipLaunchKernelGGL(thin_tiled_wgrad_kernel<13>, dim3(blocks), dim3(512), lds, st, a);
+  static const int no_static = getenv("S2P_NO_THIN_STATIC") ? 1 : 0;
+  if (d->KH == 7 && d->Cin == 64 && !no_static) hipLaunchKernelGGL((thin_tiled_wgrad_kernel<25, 7, 64>), dim3(blocks), dim3(512), lds, st, a);
+  else if (pairs <= 8 * 13) hipLaunchKernelGGL(thin_tiled_wgrad_kernel<13>, dim3(blocks), dim3(512), lds, st, a);
   else if (pairs <= 8 * 25) hipLaunchKernelGGL(thin_tiled_wgrad_kernel<25>, dim3(blocks), dim3(512), lds, st, a);
   else hipLaunchKernelGGL(thin_tiled_wgrad_kernel<32>, dim3(blocks), dim3(512), lds, st, a);
   S2P_CHECK_LAUNCH("thin_tiled_wgrad_kernel");
