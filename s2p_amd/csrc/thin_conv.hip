@@ -94,17 +94,32 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinArgs a) {
   const int m_begin = blockIdx.y * a.rows_per_block;
   int m_end = m_begin + a.rows_per_block; if (m_end > a.M) m_end = a.M;
   const int HoWo = a.Ho * a.Wo;
-  int n = m_begin / HoWo, rr = m_begin - n * HoWo, oy = rr / a.Wo, ox = rr - oy * a.Wo;
-  for (int m = m_begin; m < m_end; ++m) {
-    int iy = oy * a.stride + ky - a.pad, ix = ox * a.stride + kx - a.pad;
-    if (a.reflect) {
-      iy = iy < 0 ? -iy : (iy >= a.H ? 2 * a.H - 2 - iy : iy);
-      ix = ix < 0 ? -ix : (ix >= a.W ? 2 * a.W - 2 - ix : ix);
+  // U pixels per trip: their x / dY loads are all issued before the first FMA (one dependent load per iteration left the
+  // kernel latency-bound: ~56 iterations x one L2/HBM latency each)
+  constexpr int U = 8;
+  for (int m0 = m_begin; m0 < m_end; m0 += U) {
+    u32x4 xr[U], dr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int m = m0 + u;
+      xr[u] = (u32x4){0u, 0u, 0u, 0u}; dr[u] = (u32x4){0u, 0u, 0u, 0u};
+      if (m < m_end) {
+        const int n = m / HoWo, rr = m - n * HoWo, oy = rr / a.Wo, ox = rr - oy * a.Wo;
+        int iy = oy * a.stride + ky - a.pad, ix = ox * a.stride + kx - a.pad;
+        if (a.reflect) {
+          iy = iy < 0 ? -iy : (iy >= a.H ? 2 * a.H - 2 - iy : iy);
+          ix = ix < 0 ? -ix : (ix >= a.W ? 2 * a.W - 2 - ix : ix);
+        }
+        if (pok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+          xr[u] = *(const u32x4*)(a.x + (((size_t)n * a.H + iy) * a.W + ix) * a.x_pitch + ch * 8);
+          dr[u] = *(const u32x4*)(a.dy + (size_t)m * a.y_pitch);          // same address for the whole block: broadcast
+        }
+      }
     }
-    if (pok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
       Chunk<__bf16> xv, dv;
-      xv.raw = *(const u32x4*)(a.x + (((size_t)n * a.H + iy) * a.W + ix) * a.x_pitch + ch * 8);
-      dv.raw = *(const u32x4*)(a.dy + (size_t)m * a.y_pitch);          // same address for the whole block: broadcast
+      xv.raw = xr[u]; dv.raw = dr[u];
       float xf[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) xf[e] = xv.get(e);
@@ -116,7 +131,6 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinArgs a) {
           for (int e = 0; e < 8; ++e) acc[co][e] += d * xf[e];
         }
     }
-    if (++ox == a.Wo) { ox = 0; if (++oy == a.Ho) { oy = 0; ++n; } }
   }
   if (pok) {
 #pragma unroll
