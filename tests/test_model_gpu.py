@@ -123,6 +123,28 @@ def test_walker_state_dim_forward(hip_device, tmp_path):
     assert rel(y.cpu(), y_ref) < 1e-3
 
 
+@pytest.mark.parametrize("N,S", [(1, 100), (3, 44)])
+def test_edge_shapes_generator_and_discriminator_features(hip_device, tmp_path, N, S):
+    """Batch 1 at 100x100 (the dataset's native frame size, odd 25x25 bottleneck, odd D feature maps 51/26/14/15/16) and a
+    small odd batch at 44x44 (11x11 bottleneck: tiles spanning several images): generator output and EVERY multiscale
+    discriminator feature map against the oracle, fp32, 1e-3."""
+    opt, model, spec, pg, pd, pv = build("fp32", tmp_path)
+    prev, state, real = make_inputs(N, S, S, 17, seed=21)
+    with torch.no_grad():
+        y = model.netG(prev.cuda(), state.cuda())
+        y_ref = O.generator_forward(pg, prev, state, spec)
+        assert y.shape == y_ref.shape and rel(y.cpu(), y_ref) < 1e-3
+        x = torch.cat([prev, real], 1)
+        feats = model.netD(x.cuda())
+        feats_ref = O.multiscale_discriminator(pd, x, spec)
+    assert len(feats) == len(feats_ref) == 2
+    for fs, fr in zip(feats, feats_ref):
+        assert len(fs) == len(fr)
+        for f, r_ in zip(fs, fr):
+            assert f.shape == r_.shape, (f.shape, r_.shape)
+            assert rel(f.cpu(), r_) < 1e-3
+
+
 @pytest.mark.parametrize("precision,tol,gtol", [("fp32", 2e-3, 2e-2), ("bf16", 8e-2, 0.7)])
 def test_train_step_losses_and_grads(hip_device, tmp_path, precision, tol, gtol):
     opt, model, spec, pg, pd, pv = build(precision, tmp_path)
