@@ -267,6 +267,10 @@ def main():
         for r in recs:
             gk = groups.setdefault((r["kind"], r["shape"]), [0.0, 0.0, 0])
             gk[0] += r["flops"]; gk[1] += r["events"][0].elapsed_time(r["events"][1]); gk[2] += 1
+        if os.environ.get("S2P_BENCH_LAYERS"):           # per-layer table of the instrumented step (stderr)
+            for (gk, gshape), gv in sorted(groups.items(), key=lambda kv: -kv[1][1]):
+                print("[bench] %-6s %-44s n=%2d  %7.3f ms  %6.0f TFLOP/s" % (gk, str(gshape), gv[2], gv[1], gv[0] / (gv[1] * 1e-3) / 1e12),
+                      file=sys.stderr)
         (dk, dshape), dv = max(groups.items(), key=lambda kv: kv[1][1])
         dominant = dict(kind=dk, shape_N_H_W_Cin_Cout_k_stride_groups_transposed=list(dshape), launches_per_step=dv[2],
                         avg_launch_us=round(dv[1] * 1e3 / dv[2], 2), gflop_per_launch=round(dv[0] / dv[2] / 1e9, 2),
