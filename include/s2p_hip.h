@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define S2P_VERSION 100
+#define S2P_VERSION 101
 
 enum { S2P_F32 = 0, S2P_BF16 = 1 };
 enum { S2P_ACT_NONE = 0, S2P_ACT_RELU = 1, S2P_ACT_LRELU = 2, S2P_ACT_TANH = 3, S2P_ACT_SWISH = 4 };
@@ -90,8 +90,13 @@ int s2p_channel_sum(int dtype, const void* dy, int64_t pixels, int C, int pitch,
 
 /* ---- instance norm + MAT/SPADE modulation (replaces F.instance_norm + the elementwise
  *      `normalized * (1 + gamma) + beta` + activation of the SPADE-lineage norm) -------- */
-/* stats[n][c] += {sum x, sum x^2} over HW (raw moments; caller zeroes stats first;
- * consumers derive mean and rstd = rsqrt(biased var + eps))                             */
+/* Per-(n,c) statistics of x over the HW pixels of each image.  `stats` is an OPAQUE fp32 buffer of
+ * s2p_in_stats_floats(N,HW,C) elements, written (not accumulated: no zero-init needed) by s2p_in_stats and read by
+ * the three consumers below with the SAME (N,HW,C): per-split partial moments {mean_b, M2_b} about a pivot, merged
+ * by the consumers in a fixed order (no atomics: bitwise reproducible; no cancellation for |mean| >> std).
+ * The buffer is self-describing (it starts with its split geometry): a consumer may be called on a batch PREFIX
+ * (N' <= N images of the same x) with the same buffer.  Consumers use mean and rstd = 1/sqrt(biased var + eps). */
+int64_t s2p_in_stats_floats(int N, int HW, int C);
 int s2p_in_stats(int dtype, const void* x, int N, int HW, int C, int pitch, float eps,
                  float* stats, void* stream);
 /* y = act(xhat*(1+g_img+g_st) + (b_img+b_st)).  gb_img: [N,HW,gb_pitch] with gamma at
@@ -101,8 +106,12 @@ int s2p_in_apply_fwd(int dtype, const void* x, int N, int HW, int C, int pitch,
                      const float* stats, const void* gb_img, int gb_pitch,
                      const float* gb_st, int gb_st_pitch, int act, float slope, float eps,
                      void* y, int y_pitch, void* stream);
-/* backward, given da = dL/dy (post-activation).  sums[n][c] = {S1,S2,dgamma_st,dbeta_st}
- * must be zeroed by the caller before s2p_in_bwd_reduce.                                */
+/* backward, given da = dL/dy (post-activation).  `sums` is an OPAQUE fp32 buffer of
+ * s2p_in_bwd_sums_floats(N,HW,C) elements (per-split partial backward sums; written by
+ * s2p_in_bwd_reduce, read by s2p_in_bwd_apply; no zero-init needed).
+ * s2p_in_bwd_apply writes dx, d(gamma_img | beta_img) into dgb_img (layout of gb_img; may be NULL)
+ * and d(gamma_st | beta_st) into dgb_st (fp32 [N][dgb_st_pitch], layout of gb_st; may be NULL). */
+int64_t s2p_in_bwd_sums_floats(int N, int HW, int C);
 int s2p_in_bwd_reduce(int dtype, const void* da, int da_pitch, const void* x, int N, int HW, int C,
                       int pitch, const float* stats, const void* gb_img, int gb_pitch,
                       const float* gb_st, int gb_st_pitch, int act, float slope, float eps,
@@ -111,7 +120,7 @@ int s2p_in_bwd_apply(int dtype, const void* da, int da_pitch, const void* x, int
                      int pitch, const float* stats, const void* gb_img, int gb_pitch,
                      const float* gb_st, int gb_st_pitch, int act, float slope, float eps,
                      const float* sums, void* dx, int dx_pitch, void* dgb_img, int dgb_pitch,
-                     void* stream);
+                     float* dgb_st, int dgb_st_pitch, void* stream);
 
 /* ---- state path: positional encoding (nerf-pytorch embedder)  ------------------------ */
 /* out[n][0:S]=s, then for k<L: sin(2^k s), cos(2^k s); columns >= S*(1+2L) up to out_pitch

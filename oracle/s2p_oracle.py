@@ -168,10 +168,56 @@ def positional_encoding(s, L):
     return torch.cat(out, dim=1)
 
 
-def state_mapping(p, state, spec):
+def _act(x, kind, name, trace=None, masks=None):
+    """ReLU / LeakyReLU(0.2) of a named pre-activation.  `trace` (dict) records the pre-activation under `name`.
+    `masks` (dict name -> bool tensor) replaces the data-dependent branch `x > 0` by a given mask, which makes the
+    network a smooth function of its parameters: the parity tests pass the masks the HIP forward actually took, so a
+    pre-activation that rounds to the other side of 0 (|x| ~ 1e-7) does not show up as a gradient difference."""
+    if trace is not None:
+        trace[name] = x
+    neg = 0.0 if kind == "relu" else LRELU
+    if masks is not None and name in masks:
+        return torch.where(masks[name], x, x * neg)
+    return F.relu(x) if kind == "relu" else F.leaky_relu(x, LRELU)
+
+
+def _pool(x, name, trace=None, masks=None):
+    """F.max_pool2d(x, 2, 2); with `masks[name]` = int64 [N,C,H/2,W/2] window positions (0..3, row-major inside the
+    2x2 window) the selection is taken from the mask instead of the data (see `_act`)."""
+    N, C, H, W = x.shape
+    Ho, Wo = H // 2, W // 2
+    win = x[:, :, :Ho * 2, :Wo * 2].reshape(N, C, Ho, 2, Wo, 2).permute(0, 1, 2, 4, 3, 5).reshape(N, C, Ho, Wo, 4)
+    if trace is not None:
+        trace[name] = win.detach().argmax(4)
+    if masks is not None and name in masks:
+        return win.gather(4, masks[name].unsqueeze(-1)).squeeze(-1)
+    return F.max_pool2d(x, 2, 2)
+
+
+def _l1(a, b, name, masks=None, trace=None):
+    """F.l1_loss(a, b) (mean); with `masks[name]` = sign(a - b) in {-1, 0, 1} the branch of |.| is given."""
+    if trace is not None:
+        trace[name] = torch.sign(a.detach() - b.detach())
+    if masks is not None and name in masks:
+        return (masks[name].to(a.dtype) * (a - b)).mean()
+    return F.l1_loss(a, b)
+
+
+def _hinge(x, sign, name, masks=None, trace=None):
+    """mean(relu(1 + sign * x)); with `masks[name]` = (1 + sign * x > 0) the branch is given."""
+    v = 1.0 + sign * x
+    if trace is not None:
+        trace[name] = v.detach() > 0
+    if masks is not None and name in masks:
+        return (masks[name].to(x.dtype) * v).mean()
+    return F.relu(v).mean()
+
+
+def state_mapping(p, state, spec, trace=None, masks=None):
     h = positional_encoding(state, spec.posenc_L)
     for i in range(spec.n_mlp):
-        h = F.leaky_relu(F.linear(h, p[f"state_map.fc{i}.weight"], p[f"state_map.fc{i}.bias"]), LRELU)
+        h = _act(F.linear(h, p[f"state_map.fc{i}.weight"], p[f"state_map.fc{i}.bias"]), "lrelu", f"state_map.fc{i}",
+                 trace, masks)
     return h
 
 
@@ -192,26 +238,40 @@ def mat_norm(p, prefix, x, prev_image, w):
     return instance_norm(x) * (1.0 + gamma + g_st) + (beta + b_st)
 
 
-def mat_resblock(p, b, x, prev_image, w):
-    dx = F.conv2d(F.leaky_relu(mat_norm(p, f"blocks.{b}.norm_0", x, prev_image, w), LRELU),
+def mat_resblock(p, b, x, prev_image, w, trace=None, masks=None):
+    dx = F.conv2d(_act(mat_norm(p, f"blocks.{b}.norm_0", x, prev_image, w), "lrelu", f"blocks.{b}.norm_0", trace, masks),
                   p[f"blocks.{b}.conv_0.weight"], p[f"blocks.{b}.conv_0.bias"], padding=1)
-    dx = F.conv2d(F.leaky_relu(mat_norm(p, f"blocks.{b}.norm_1", dx, prev_image, w), LRELU),
+    if trace is not None:
+        trace[f"blocks.{b}.conv_0"] = dx
+    dx = F.conv2d(_act(mat_norm(p, f"blocks.{b}.norm_1", dx, prev_image, w), "lrelu", f"blocks.{b}.norm_1", trace, masks),
                   p[f"blocks.{b}.conv_1.weight"], p[f"blocks.{b}.conv_1.bias"], padding=1)
     return x + dx
 
 
-def generator_forward(p, prev_image, state, spec):
-    """netG='s2p': (prev_image [N,3,H,W] in [-1,1], state [N,S]) -> image [N,3,H,W]."""
-    w = state_mapping(p, state, spec)
+def generator_forward(p, prev_image, state, spec, trace=None, masks=None):
+    """netG='s2p': (prev_image [N,3,H,W] in [-1,1], state [N,S]) -> image [N,3,H,W].
+    `trace` / `masks`: see `_act` (pre-activations named stem, down{i}, blocks.{b}.norm_{j}, up{i}; the trace also holds
+    the raw conv outputs `<name>.conv`, `blocks.{b}.conv_0`, `blocks.{b}.out` and the state code `w`)."""
+    w = state_mapping(p, state, spec, trace, masks)
     x = F.conv2d(F.pad(prev_image, (3, 3, 3, 3), mode="reflect"), p["stem.weight"])
-    x = F.relu(instance_norm(x))
+    if trace is not None:
+        trace["w"] = w
+        trace["stem.conv"] = x
+    x = _act(instance_norm(x), "relu", "stem", trace, masks)
     for i in range(spec.n_down):
-        x = F.relu(instance_norm(F.conv2d(x, p[f"down{i}.weight"], stride=2, padding=1)))
+        x = F.conv2d(x, p[f"down{i}.weight"], stride=2, padding=1)
+        if trace is not None:
+            trace[f"down{i}.conv"] = x
+        x = _act(instance_norm(x), "relu", f"down{i}", trace, masks)
     for b in range(spec.n_blocks):
-        x = mat_resblock(p, b, x, prev_image, w)
+        x = mat_resblock(p, b, x, prev_image, w, trace, masks)
+        if trace is not None:
+            trace[f"blocks.{b}.out"] = x
     for i in range(spec.n_down):
         x = F.conv_transpose2d(x, p[f"up{i}.weight"], stride=2, padding=1, output_padding=1)
-        x = F.relu(instance_norm(x))
+        if trace is not None:
+            trace[f"up{i}.conv"] = x
+        x = _act(instance_norm(x), "relu", f"up{i}", trace, masks)
     x = F.conv2d(F.pad(x, (3, 3, 3, 3), mode="reflect"), p["out.weight"], p["out.bias"])
     return torch.tanh(x)
 
@@ -219,15 +279,17 @@ def generator_forward(p, prev_image, state, spec):
 # --------------------------------------------------------------------------- #
 # discriminator                                                                #
 # --------------------------------------------------------------------------- #
-def nlayer_discriminator(p, k, x, spec):
+def nlayer_discriminator(p, k, x, spec, trace=None, masks=None):
+    """Pre-activations are named D{k}.model{n} (see `_act`)."""
     pre = f"discriminator_{k}"
     feats = []
-    h = F.leaky_relu(F.conv2d(x, p[f"{pre}.model0.weight"], p[f"{pre}.model0.bias"], stride=2, padding=2), LRELU)
+    h = _act(F.conv2d(x, p[f"{pre}.model0.weight"], p[f"{pre}.model0.bias"], stride=2, padding=2), "lrelu",
+             f"D{k}.model0", trace, masks)
     feats.append(h)
     for n in range(1, spec.n_layers_D):
         stride = 1 if n == spec.n_layers_D - 1 else 2
         h = F.conv2d(h, p[f"{pre}.model{n}.weight"], None, stride=stride, padding=2)
-        h = F.leaky_relu(instance_norm(h), LRELU)
+        h = _act(instance_norm(h), "lrelu", f"D{k}.model{n}", trace, masks)
         feats.append(h)
     n = spec.n_layers_D
     h = F.conv2d(h, p[f"{pre}.model{n}.weight"], p[f"{pre}.model{n}.bias"], stride=1, padding=2)
@@ -235,10 +297,10 @@ def nlayer_discriminator(p, k, x, spec):
     return feats
 
 
-def multiscale_discriminator(p, x, spec):
+def multiscale_discriminator(p, x, spec, trace=None, masks=None):
     result = []
     for k in range(spec.num_D):
-        result.append(nlayer_discriminator(p, k, x, spec))
+        result.append(nlayer_discriminator(p, k, x, spec, trace, masks))
         x = F.avg_pool2d(x, kernel_size=3, stride=2, padding=1, count_include_pad=False)
     return result
 
@@ -246,24 +308,27 @@ def multiscale_discriminator(p, x, spec):
 # --------------------------------------------------------------------------- #
 # losses                                                                       #
 # --------------------------------------------------------------------------- #
-def vgg_features(p, x):
+def vgg_features(p, x, trace=None, masks=None):
+    """ReLU pre-activations are named vgg.<conv>, the pools vgg.pool{i} (see `_act`, `_pool`)."""
     feats = []
     h = x
+    npool = 0
     for item in VGG_CFG:
         if item == "P":
-            h = F.max_pool2d(h, 2, 2)
+            h = _pool(h, f"vgg.pool{npool}", trace, masks)
+            npool += 1
             continue
         name = item[0]
-        h = F.relu(F.conv2d(h, p[f"{name}.weight"], p[f"{name}.bias"], padding=1))
+        h = _act(F.conv2d(h, p[f"{name}.weight"], p[f"{name}.bias"], padding=1), "relu", f"vgg.{name}", trace, masks)
         if name in VGG_TAPS:
             feats.append(h)
     return feats
 
 
-def hinge_d_loss(pred_fake, pred_real):
+def hinge_d_loss(pred_fake, pred_real, masks=None, trace=None):
     """Mean over scales of mean(relu(1+D(fake))) / mean(relu(1-D(real))); last feature per scale."""
-    lf = sum(F.relu(1.0 + s[-1]).mean() for s in pred_fake) / len(pred_fake)
-    lr = sum(F.relu(1.0 - s[-1]).mean() for s in pred_real) / len(pred_real)
+    lf = sum(_hinge(s[-1], 1.0, f"hinge.fake{k}", masks, trace) for k, s in enumerate(pred_fake)) / len(pred_fake)
+    lr = sum(_hinge(s[-1], -1.0, f"hinge.real{k}", masks, trace) for k, s in enumerate(pred_real)) / len(pred_real)
     return lf, lr
 
 
@@ -271,48 +336,69 @@ def hinge_g_loss(pred_fake):
     return sum(-s[-1].mean() for s in pred_fake) / len(pred_fake)
 
 
-def feat_match_loss(pred_fake, pred_real, lambda_feat):
+def feat_match_loss(pred_fake, pred_real, lambda_feat, masks=None, trace=None):
     num_D = len(pred_fake)
     loss = 0.0
     for i in range(num_D):
         for j in range(len(pred_fake[i]) - 1):
-            loss = loss + F.l1_loss(pred_fake[i][j], pred_real[i][j].detach()) * lambda_feat / num_D
+            loss = loss + _l1(pred_fake[i][j], pred_real[i][j].detach(), f"l1.feat{i}.{j}", masks, trace) * lambda_feat / num_D
     return loss
 
 
-def vgg_loss(pv, fake, real):
-    ff, fr = vgg_features(pv, fake), vgg_features(pv, real)
-    return sum(w * F.l1_loss(a, b.detach()) for w, a, b in zip(VGG_WEIGHTS, ff, fr))
+def vgg_loss(pv, fake, real, masks=None, trace=None):
+    """The product runs VGG once on cat([fake; real]) along the batch: masks of a VGG layer cover both halves."""
+    n = fake.shape[0]
+    f2 = vgg_features(pv, torch.cat([fake, real], 0), trace, masks)
+    return sum(w * _l1(t[:n], t[n:].detach(), f"l1.vgg{k}", masks, trace) for k, (w, t) in enumerate(zip(VGG_WEIGHTS, f2)))
 
 
-def discriminate(pd, prev_image, fake, real, spec):
+def discriminate(pd, prev_image, fake, real, spec, masks=None, trace=None):
     """One D call on cat([fake;real]) along batch, each concatenated with the conditioning
     previous image on channels (SPEC.md D7)."""
     x = torch.cat([torch.cat([prev_image, fake], 1), torch.cat([prev_image, real], 1)], 0)
-    out = multiscale_discriminator(pd, x, spec)
+    out = multiscale_discriminator(pd, x, spec, trace, masks)
     n = fake.shape[0]
     pf = [[t[:n] for t in s] for s in out]
     pr = [[t[n:] for t in s] for s in out]
     return pf, pr
 
 
-def generator_losses(pg, pd, pv, prev_image, state, real, spec):
-    fake = generator_forward(pg, prev_image, state, spec)
-    pf, pr = discriminate(pd, prev_image, fake, real, spec)
+def generator_losses(pg, pd, pv, prev_image, state, real, spec, masks=None, trace=None):
+    """`masks`: optional branch masks for every data-dependent branch of the step (see `_act`, `_pool`, `_l1`);
+    `trace` records the branches actually taken (`branch_masks` turns such a trace into masks)."""
+    fake = generator_forward(pg, prev_image, state, spec, trace, masks)
+    pf, pr = discriminate(pd, prev_image, fake, real, spec, masks, trace)
     losses = OrderedDict()
     losses["GAN"] = hinge_g_loss(pf)
-    losses["GAN_Feat"] = feat_match_loss(pf, pr, spec.lambda_feat)
+    losses["GAN_Feat"] = feat_match_loss(pf, pr, spec.lambda_feat, masks, trace)
     if pv is not None:
-        losses["VGG"] = vgg_loss(pv, fake, real) * spec.lambda_vgg
-    losses["L1"] = F.l1_loss(fake, real) * spec.lambda_l1
+        losses["VGG"] = vgg_loss(pv, fake, real, masks, trace) * spec.lambda_vgg
+    losses["L1"] = _l1(fake, real, "l1.pix", masks, trace) * spec.lambda_l1
     return losses, fake
 
 
-def discriminator_losses(pg, pd, prev_image, state, real, spec):
-    with torch.no_grad():
-        fake = generator_forward(pg, prev_image, state, spec)
-    pf, pr = discriminate(pd, prev_image, fake.detach(), real, spec)
-    lf, lr = hinge_d_loss(pf, pr)
+def branch_masks(trace):
+    """Turn a trace into the mask dict that reproduces the same branches: pre-activations -> (x > 0); pool indices,
+    L1 signs and hinge masks are recorded in mask form already.  Raw conv outputs etc. are dropped."""
+    m = {}
+    for k, v in trace.items():
+        if k.startswith(("l1.", "hinge.", "vgg.pool")):
+            m[k] = v
+        elif k == "w" or k.endswith((".conv", ".conv_0", ".out")):
+            continue
+        else:
+            m[k] = v.detach() > 0
+    return m
+
+
+def discriminator_losses(pg, pd, prev_image, state, real, spec, masks=None, fake=None, trace=None):
+    """`fake`: optional pre-computed generator output (the parity tests pass the HIP generator's own output so that the
+    D-step comparison isolates the discriminator path)."""
+    if fake is None:
+        with torch.no_grad():
+            fake = generator_forward(pg, prev_image, state, spec)
+    pf, pr = discriminate(pd, prev_image, fake.detach(), real, spec, masks, trace)
+    lf, lr = hinge_d_loss(pf, pr, masks, trace)
     return OrderedDict(D_Fake=lf, D_real=lr)
 
 

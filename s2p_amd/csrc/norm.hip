@@ -1,28 +1,64 @@
 // InstanceNorm + MAT/SPADE modulation for NHWC tensors on gfx950.  HBM-bound: every tensor is touched with
 // 16-byte chunks along the contiguous channel axis; per-(n,c) reductions are done per thread over a pixel
-// stripe, then across stripes through LDS, then across blocks with one fp32 atomic per (n,c,quantity).
+// stripe, then across stripes through LDS (fixed order), then across the workgroups of a plane by the CONSUMER,
+// again in a fixed order.  No atomics anywhere: results are bitwise reproducible run to run.
 //
-//   stats[n][c] = { sum x, sum x^2 }   (raw moments; consumers derive mean / rstd; this form lets a
-//                                       producer epilogue accumulate the moments instead of a stats pass)
+//   stats  : opaque fp32 buffer: a 4-word header {S, rows per split, 0, 0} followed by [N][C][S][2] per-split partial
+//            moments {mean_b, M2_b}.  A split accumulates sum(x-K), sum((x-K)^2) about a pivot K = its first pixel
+//            (no cancellation for |mean| >> std), converts to (mean_b, M2_b); consumers merge the S partials with
+//            Chan's formula.  The header makes the buffer self-describing: a batch prefix (the first n images) is a
+//            valid stats buffer for that prefix whatever split count the consumer's own launch would pick.
+//   sums   : opaque fp32 buffer [N][C][S][4] of per-split backward sums, summed by the consumer in split order.
 //   y  = act( xhat * (1 + g_img + g_st) + (b_img + b_st) ),   xhat = (x - mean) * rstd
 #include "s2p_common.h"
 #include <stdlib.h>
 
 struct NormArgs {
   const void* x; const void* da; const void* gb; const float* gbst; const float* stats; float* sums;
-  void* y; void* dgb;
-  int N, HW, C, x_pitch, da_pitch, gb_pitch, gbst_pitch, y_pitch, dgb_pitch;
+  void* y; void* dgb; float* dgbst;
+  int N, HW, C, x_pitch, da_pitch, gb_pitch, gbst_pitch, y_pitch, dgb_pitch, dgbst_pitch;
   int act; float slope, eps;
-  int psplit, rows_per_split;
+  int psplit, rows_per_split;       // geometry of THIS launch
+  int q_split;                      // geometry of the backward-sum partials (bwd apply merges q_split entries)
 };
+constexpr int STATS_HDR = 4;        // header words in front of the partial moments
 
-__device__ __forceinline__ void mean_rstd(const float* stats, int n, int C, int c, int HW, float eps,
-                                          float& mean, float& rstd) {
-  float s = stats[((size_t)n * C + c) * 2], ss = stats[((size_t)n * C + c) * 2 + 1];
-  float inv = 1.f / (float)HW;
-  mean = s * inv;
-  float var = ss * inv - mean * mean;
-  rstd = rsqrtf((var > 0.f ? var : 0.f) + eps);
+// split geometry of the reductions: aim at >= 1024 workgroups, at least 128 pixels per split
+static inline int stats_splits(int N, int HW, int C) {
+  int slabs = cdiv(C, 64);
+  int ps = cdiv(1024, slabs * N);
+  int maxps = cdiv(HW, 128); if (ps > maxps) ps = maxps; if (ps < 1) ps = 1;
+  int rows = cdiv(HW, ps);
+  return cdiv(HW, rows);
+}
+
+// merge the per-split partial moments of channel c of image n (fixed order: bitwise reproducible)
+__device__ __forceinline__ void mean_rstd(const NormArgs& a, int n, int c, float& mean, float& rstd) {
+  const int S = ((const int*)a.stats)[0], rows = ((const int*)a.stats)[1];
+  const float* p = a.stats + STATS_HDR + ((size_t)n * a.C + c) * S * 2;
+  const float inv = 1.f / (float)a.HW;
+  const float m0 = p[0];                               // merge about the first split's mean: the differences are O(std)
+  float m = 0.f;
+  for (int b = 1; b < S; ++b) {
+    int nb = a.HW - b * rows; if (nb > rows) nb = rows;
+    m += (float)nb * (p[2 * b] - m0);
+  }
+  m = m0 + m * inv;
+  float M2 = 0.f;
+  for (int b = 0; b < S; ++b) {
+    int nb = a.HW - b * rows; if (nb > rows) nb = rows;
+    const float d = p[2 * b] - m;
+    M2 += p[2 * b + 1] + (float)nb * d * d;
+  }
+  mean = m;
+  rstd = 1.f / sqrtf(M2 * inv + a.eps);
+}
+
+// the modulated value, written ONCE so that forward, backward-reduce and backward-apply round identically (the
+// backward re-derives the activation mask from it)
+__device__ __forceinline__ float mat_value(float x, float mean, float rstd, float gg, float bb, float& xh) {
+  xh = (x - mean) * rstd;
+  return __builtin_fmaf(xh, gg, bb);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -35,6 +71,7 @@ __global__ __launch_bounds__(256) void in_reduce_kernel(const NormArgs a) {
   constexpr int PR = 256 / NCH;          // pixel rows in flight: 32 / 16
   constexpr int NQ = MODE == 0 ? 2 : 4;
   __shared__ float red[PR][CS + 1];
+  __shared__ float cst[4][CS];
   const int tid = threadIdx.x, cc = tid % NCH, pr = tid / NCH;
   const int n = blockIdx.y, c0 = blockIdx.x * CS + cc * CE;
   const bool cok = c0 < a.C;
@@ -51,15 +88,15 @@ __global__ __launch_bounds__(256) void in_reduce_kernel(const NormArgs a) {
   float mean[CE], rstd[CE], gs[CE], bs[CE];
   // activation selectors resolved once per thread (a per-element switch on a kernel argument is scalar-branch bound)
   const float gneg = a.act == S2P_ACT_RELU ? 0.f : (a.act == S2P_ACT_LRELU ? a.slope : 1.f);
+  const T* xb = (const T*)a.x + (size_t)n * a.HW * a.x_pitch + c0;
   if (MODE == 1) {
     // per-(n, channel) constants: computed by 64 threads once per workgroup and shared through LDS (a thread walks
     // only a few pixels, so 4*CE global loads + CE rsqrt per thread would cost as much as its payload)
-    __shared__ float cst[4][CS];
     if (tid < CS) {
       const int c = blockIdx.x * CS + tid;
       float m = 0.f, r = 0.f, g1 = 1.f, b1 = 0.f;
       if (c < a.C) {
-        mean_rstd(a.stats, n, a.C, c, a.HW, a.eps, m, r);
+        mean_rstd(a, n, c, m, r);
         if (a.gbst) { g1 = 1.f + a.gbst[(size_t)n * a.gbst_pitch + c]; b1 = a.gbst[(size_t)n * a.gbst_pitch + a.C + c]; }
       }
       cst[0][tid] = m; cst[1][tid] = r; cst[2][tid] = g1; cst[3][tid] = b1;
@@ -69,14 +106,23 @@ __global__ __launch_bounds__(256) void in_reduce_kernel(const NormArgs a) {
     for (int e = 0; e < CE; ++e) {
       mean[e] = cst[0][cc * CE + e]; rstd[e] = cst[1][cc * CE + e]; gs[e] = cst[2][cc * CE + e]; bs[e] = cst[3][cc * CE + e];
     }
+  } else {
+    // pivot = the split's first pixel (every stripe of the workgroup reads the same 16 bytes)
+    Chunk<T> kv; kv.raw = (u32x4){0u, 0u, 0u, 0u};
+    if (cok) kv.raw = *(const u32x4*)(xb + (size_t)p_begin * a.x_pitch);
+#pragma unroll
+    for (int e = 0; e < CE; ++e) mean[e] = kv.get(e);
+    if (pr == 0) {
+#pragma unroll
+      for (int e = 0; e < CE; ++e) cst[0][cc * CE + e] = mean[e];
+    }
   }
   if (cok) {
-    const T* xb = (const T*)a.x + (size_t)n * a.HW * a.x_pitch + c0;
     for (int p = p_begin + pr; p < p_end; p += PR) {
       Chunk<T> xv; xv.raw = *(const u32x4*)(xb + (size_t)p * a.x_pitch);
-      if (MODE == 0) {
+      if constexpr (MODE == 0) {
 #pragma unroll
-        for (int e = 0; e < CE; ++e) { float v = xv.get(e); q[0][e] += v; q[1][e] += v * v; }
+        for (int e = 0; e < CE; ++e) { float v = xv.get(e) - mean[e]; q[0][e] += v; q[1][e] = __builtin_fmaf(v, v, q[1][e]); }
       } else {
         Chunk<T> dv; dv.raw = *(const u32x4*)((const T*)a.da + ((size_t)n * a.HW + p) * a.da_pitch + c0);
         Chunk<T> gv, bv;
@@ -86,10 +132,10 @@ __global__ __launch_bounds__(256) void in_reduce_kernel(const NormArgs a) {
         }
 #pragma unroll
         for (int e = 0; e < CE; ++e) {
-          float xh = (xv.get(e) - mean[e]) * rstd[e];
           float gg = gs[e] + (a.gb ? gv.get(e) : 0.f);
           float bb = bs[e] + (a.gb ? bv.get(e) : 0.f);
-          float yv = xh * gg + bb;
+          float xh;
+          float yv = mat_value(xv.get(e), mean[e], rstd[e], gg, bb, xh);
           float dy = dv.get(e) * (yv > 0.f ? 1.f : gneg);
           float dxh = dy * gg;
           q[0][e] += dxh; q[1][e] += dxh * xh; q[2][e] += dy * xh; q[3][e] += dy;
@@ -97,20 +143,35 @@ __global__ __launch_bounds__(256) void in_reduce_kernel(const NormArgs a) {
       }
     }
   }
-  // cross-stripe reduction through LDS, one quantity at a time
-  float* out = MODE == 0 ? (float*)a.stats : a.sums;
+  // cross-stripe reduction through LDS, one quantity at a time, in stripe order
+  float tot[NQ];
 #pragma unroll
   for (int k = 0; k < NQ; ++k) {
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < CE; ++e) red[pr][cc * CE + e] = q[k][e];
     __syncthreads();
+    float s = 0.f;
     if (tid < CS) {
-      float s = 0.f;
 #pragma unroll 4
       for (int i = 0; i < PR; ++i) s += red[i][tid];
-      int c = blockIdx.x * CS + tid;
-      if (c < a.C) atomicAdd(out + ((size_t)n * a.C + c) * NQ + k, s);
+    }
+    tot[k] = s;
+  }
+  if (tid < CS) {
+    const int c = blockIdx.x * CS + tid;
+    if (c < a.C) {
+      if constexpr (MODE == 0) {
+        const float nb = (float)(p_end - p_begin);
+        const float d = tot[0] / nb;                       // mean_b - pivot
+        float M2 = tot[1] - tot[0] * d;
+        float* o = (float*)a.stats + STATS_HDR + (((size_t)n * a.C + c) * a.psplit + blockIdx.z) * 2;
+        o[0] = cst[0][tid] + d; o[1] = M2 > 0.f ? M2 : 0.f;
+        if (c == 0 && n == 0 && blockIdx.z == 0) { ((int*)a.stats)[0] = a.psplit; ((int*)a.stats)[1] = a.rows_per_split; }
+      } else {
+        float* o = a.sums + (((size_t)n * a.C + c) * a.psplit + blockIdx.z) * 4;
+        *(f32x4*)o = (f32x4){tot[0], tot[1], tot[2], tot[3]};
+      }
     }
   }
 }
@@ -118,7 +179,7 @@ __global__ __launch_bounds__(256) void in_reduce_kernel(const NormArgs a) {
 // ------------------------------------------------------------------------------------------------
 // elementwise passes.  MODE 0: forward apply.  MODE 1: backward apply (dx, dgamma_img, dbeta_img).
 // Same thread geometry as the reductions: a thread owns one 16-byte channel chunk of one image and walks a pixel
-// stripe, so every per-(n,c) constant (mean, rstd, state gamma/beta, backward sums) is computed ONCE per thread and
+// stripe, so every per-(n,c) constant (mean, rstd, state gamma/beta, backward sums) is computed ONCE per workgroup and
 // the loop body is pure streaming: 16-B loads, a few FMAs per element, 16-B stores.
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void in_apply_kernel(const NormArgs a) {
@@ -136,9 +197,19 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const NormArgs a) {
     const int c = blockIdx.x * CS + tid;
     float m = 0.f, r = 0.f, g1 = 1.f, b1 = 0.f, q1 = 0.f, q2 = 0.f;
     if (c < a.C) {
-      mean_rstd(a.stats, n, a.C, c, a.HW, a.eps, m, r);
+      mean_rstd(a, n, c, m, r);
       if (a.gbst) { g1 = 1.f + a.gbst[(size_t)n * a.gbst_pitch + c]; b1 = a.gbst[(size_t)n * a.gbst_pitch + a.C + c]; }
-      if (MODE == 1) { const float* sm = a.sums + ((size_t)n * a.C + c) * 4; q1 = sm[0] * invHW; q2 = sm[1] * invHW; }
+      if (MODE == 1) {
+        const float* sm = a.sums + ((size_t)n * a.C + c) * a.q_split * 4;
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+        for (int b = 0; b < a.q_split; ++b) { t0 += sm[4 * b]; t1 += sm[4 * b + 1]; t2 += sm[4 * b + 2]; t3 += sm[4 * b + 3]; }
+        q1 = t0 * invHW; q2 = t1 * invHW;
+        // gradient of the per-sample state affine (gamma_st | beta_st): one workgroup per (n, slab) stores it
+        if (a.dgbst && blockIdx.z == 0) {
+          a.dgbst[(size_t)n * a.dgbst_pitch + c] = t2;
+          a.dgbst[(size_t)n * a.dgbst_pitch + a.C + c] = t3;
+        }
+      }
     }
     cst[0][tid] = m; cst[1][tid] = r; cst[2][tid] = g1; cst[3][tid] = b1; cst[4][tid] = q1; cst[5][tid] = q2;
   }
@@ -171,8 +242,8 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const NormArgs a) {
     for (int e = 0; e < CE; ++e) {
       float gg = gs[e] + (gbb ? gv.get(e) : 0.f);
       float bb = bs[e] + (gbb ? bv.get(e) : 0.f);
-      float xh = (xv.get(e) - mean[e]) * rstd[e];
-      float yv = xh * gg + bb;
+      float xh;
+      float yv = mat_value(xv.get(e), mean[e], rstd[e], gg, bb, xh);
       if (MODE == 0) {
         o0.set(e, yv > 0.f ? yv : yv * ns);
       } else {
@@ -188,7 +259,8 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const NormArgs a) {
       for (int e = 0; e < CE; ++e) {
         float gg = gs[e] + (gbb ? gv.get(e) : 0.f);
         float bb = bs[e] + (gbb ? bv.get(e) : 0.f);
-        o0.set(e, act_fwd((xv.get(e) - mean[e]) * rstd[e] * gg + bb, a.act, a.slope));
+        float xh;
+        o0.set(e, act_fwd(mat_value(xv.get(e), mean[e], rstd[e], gg, bb, xh), a.act, a.slope));
       }
     }
     *(u32x4*)(yb + (size_t)p * a.y_pitch) = o0.raw;
@@ -245,10 +317,9 @@ static int norm_check(const char* who, int dtype, int C, int p0, int p1, int p2)
 template <int MODE>
 static int launch_reduce(int dtype, NormArgs& a, hipStream_t st) {
   int slabs = cdiv(a.C, 64);
-  int ps = cdiv(1024, slabs * a.N);                     // aim at >= 1024 workgroups
-  int maxps = cdiv(a.HW, 128); if (ps > maxps) ps = maxps; if (ps < 1) ps = 1;
-  a.psplit = ps; a.rows_per_split = cdiv(a.HW, ps);
-  dim3 grid(slabs, a.N, cdiv(a.HW, a.rows_per_split));
+  a.psplit = stats_splits(a.N, a.HW, a.C); a.rows_per_split = cdiv(a.HW, a.psplit);
+  a.q_split = a.psplit;
+  dim3 grid(slabs, a.N, a.psplit);
   if (dtype == S2P_F32) hipLaunchKernelGGL((in_reduce_kernel<float, MODE>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((in_reduce_kernel<__bf16, MODE>), grid, dim3(256), 0, st, a);
   S2P_CHECK_LAUNCH("in_reduce_kernel");
@@ -258,8 +329,8 @@ static int launch_reduce(int dtype, NormArgs& a, hipStream_t st) {
 template <int MODE>
 static int launch_apply(int dtype, NormArgs& a, hipStream_t st) {
   int slabs = cdiv(a.C, 64);
-  static const int target = getenv("S2P_NORM_BLOCKS") ? atoi(getenv("S2P_NORM_BLOCKS")) : 1024;
-  int ps = cdiv(target, slabs * a.N);                   // aim at >= `target` workgroups
+  a.q_split = stats_splits(a.N, a.HW, a.C);             // geometry of the backward-sum partials of the same call
+  int ps = cdiv(1024, slabs * a.N);                     // aim at >= 1024 workgroups
   int maxps = cdiv(a.HW, 64); if (ps > maxps) ps = maxps; if (ps < 1) ps = 1;
   a.psplit = ps; a.rows_per_split = cdiv(a.HW, ps);
   dim3 grid(slabs, a.N, cdiv(a.HW, a.rows_per_split));
@@ -269,9 +340,20 @@ static int launch_apply(int dtype, NormArgs& a, hipStream_t st) {
   return 0;
 }
 
+extern "C" int64_t s2p_in_stats_floats(int N, int HW, int C) {
+  if (N <= 0 || HW <= 0 || C <= 0) return 0;
+  return STATS_HDR + (int64_t)N * C * stats_splits(N, HW, C) * 2;
+}
+
+extern "C" int64_t s2p_in_bwd_sums_floats(int N, int HW, int C) {
+  if (N <= 0 || HW <= 0 || C <= 0) return 0;
+  return (int64_t)N * C * stats_splits(N, HW, C) * 4;
+}
+
 extern "C" int s2p_in_stats(int dtype, const void* x, int N, int HW, int C, int pitch, float eps, float* stats,
                             void* stream) {
   int rc = norm_check("s2p_in_stats", dtype, C, pitch, 0, 0); if (rc) return rc;
+  if (!x || !stats || N <= 0 || HW <= 0) S2P_FAIL(-1, "s2p_in_stats: null pointer / empty problem");
   NormArgs a{}; a.x = x; a.stats = stats; a.N = N; a.HW = HW; a.C = C; a.x_pitch = pitch; a.eps = eps;
   return launch_reduce<0>(dtype, a, (hipStream_t)stream);
 }
@@ -301,12 +383,13 @@ extern "C" int s2p_in_bwd_apply(int dtype, const void* da, int da_pitch, const v
                                 int pitch, const float* stats, const void* gb_img, int gb_pitch,
                                 const float* gb_st, int gb_st_pitch, int act, float slope, float eps,
                                 const float* sums, void* dx, int dx_pitch, void* dgb_img, int dgb_pitch,
-                                void* stream) {
+                                float* dgb_st, int dgb_st_pitch, void* stream) {
   int rc = norm_check("s2p_in_bwd_apply", dtype, C, pitch, gb_pitch, da_pitch); if (rc) return rc;
   if (dx_pitch % (dtype == S2P_F32 ? 4 : 8) || dgb_pitch % (dtype == S2P_F32 ? 4 : 8))
     S2P_FAIL(-1, "s2p_in_bwd_apply: bad output pitch");
+  if (dgb_st && dgb_st_pitch < 2 * C) S2P_FAIL(-1, "s2p_in_bwd_apply: dgb_st pitch < 2*C");
   NormArgs a{}; a.x = x; a.da = da; a.stats = stats; a.gb = gb_img; a.gbst = gb_st; a.sums = (float*)sums;
-  a.y = dx; a.dgb = dgb_img;
+  a.y = dx; a.dgb = dgb_img; a.dgbst = dgb_st; a.dgbst_pitch = dgb_st_pitch;
   a.N = N; a.HW = HW; a.C = C; a.x_pitch = pitch; a.da_pitch = da_pitch; a.gb_pitch = gb_pitch;
   a.gbst_pitch = gb_st_pitch; a.y_pitch = dx_pitch; a.dgb_pitch = dgb_pitch; a.act = act; a.slope = slope;
   a.eps = eps;

@@ -62,9 +62,10 @@ class S2PDataset(torch.utils.data.Dataset):
         if self.states.shape[1] != opt.state_dim:
             raise ValueError("dataset state dim %d != --state_dim %d" % (self.states.shape[1], opt.state_dim))
         timeouts = arr.get("timeouts")
+        self.timeouts = None if timeouts is None else np.asarray(timeouts).astype(bool).reshape(-1)
         valid = np.ones(T - 1, dtype=bool)
         if timeouts is not None:
-            valid &= ~np.asarray(timeouts[:-1]).astype(bool)      # no pair across an episode boundary
+            valid &= ~self.timeouts[:-1]                          # no pair across an episode boundary
         self.index = np.nonzero(valid)[0][: opt.max_dataset_size]
         self.size = opt.crop_size
 
@@ -80,6 +81,11 @@ class S2PDataset(torch.utils.data.Dataset):
         """Frames/states [start, start+length] for an autoregressive rollout."""
         if start + length >= len(self.images):
             raise IndexError("sequence [%d,%d] exceeds dataset length %d" % (start, start + length, len(self.images)))
+        if self.timeouts is not None and self.timeouts[start:start + length].any():
+            # frame t+1 after a timeout at t belongs to the next episode: the rollout would be scored against it
+            end = start + int(np.argmax(self.timeouts[start:start + length]))
+            raise IndexError("sequence [%d,%d] crosses an episode boundary (timeout at frame %d); use --seq_len <= %d"
+                             % (start, start + length, end, end - start))
         imgs = images_to_tensor(self.images[start:start + length + 1], self.size)
         return imgs, torch.from_numpy(self.states[start:start + length + 1])
 

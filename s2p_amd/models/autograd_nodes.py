@@ -23,7 +23,6 @@ class _GeneratorNode(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, prev_image, state, net, save):
         dt = net.compute_dtype
-        ops.arena_begin(prev_image.device)
         img = ops.nchw_to_nhwc(prev_image.float(), dt, chunk_elems(dt))
         out, c = net.fwd_nhwc(img, state.float(), save=save)
         ctx.net, ctx.c = net, c
@@ -33,7 +32,6 @@ class _GeneratorNode(torch.autograd.Function):
     def backward(ctx, d_out):
         if not ctx.c:
             raise RuntimeError("generator forward was run without saving activations")
-        ops.arena_begin(d_out.device, 1 << 22)
         ctx.net.bwd_nhwc(ctx.c, d_out.contiguous())
         ctx.c = None
         return None, None, None, None, None
@@ -96,7 +94,6 @@ class _GLossNode(torch.autograd.Function):
         opt = model.opt
         N, H, W, ce = fake.shape
         dt = fake.dtype
-        ops.arena_begin(fake.device)
         losses = torch.zeros(4, dtype=torch.float32, device=fake.device)
         x = _build_d_input(model, fake, prev_image, real_image)
         res, dctx = model.netD.fwd_nhwc(x)
@@ -151,7 +148,6 @@ class _GLossNode(torch.autograd.Function):
                     ops.scale_(t, g[2:3])
             ops.scale_(ctx.d_fake, g[3:4])
         d_fake = ctx.d_fake
-        ops.arena_begin(d_fake.device)
         dx = model.netD.bwd_nhwc(ctx.dctx, ctx.grads, need_wgrad=False, need_dx=True, n_keep=N)   # fake half only
         ops.copy_channels(dx, 3, d_fake, 0, 3, accumulate=True, src_rows=N)
         if ctx.vctx is not None:
@@ -171,7 +167,6 @@ class _DLossNode(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, fake, prev_image, real_image):
         N = fake.shape[0]
-        ops.arena_begin(fake.device)
         losses = torch.zeros(2, dtype=torch.float32, device=fake.device)
         x = _build_d_input(model, fake, prev_image, real_image)
         res, dctx = model.netD.fwd_nhwc(x)
@@ -196,7 +191,6 @@ class _DLossNode(torch.autograd.Function):
                 flat = t.view(-1)
                 ops.scale_(flat[:half], g[0:1])
                 ops.scale_(flat[half:], g[1:2])
-        ops.arena_begin(dev)
         model.netD.bwd_nhwc(ctx.dctx, ctx.grads, need_wgrad=True, need_dx=False)
         ctx.dctx = ctx.grads = None
         return None, None, None, None, None

@@ -79,7 +79,8 @@ class NLayerDiscriminator(BaseNetwork):
         uses it because the real half of the D batch carries no gradient."""
         nl = self.n_layers
         if n_keep is not None:
-            saved = [tuple(None if t is None else t[:n_keep] for t in tup) for tup in saved]
+            # (the statistics buffer is self-describing and valid for a batch prefix: it is not sliced)
+            saved = [(xin[:n_keep], None if c is None else c[:n_keep], s, f[:n_keep]) for xin, c, s, f in saved]
         xin, _, _, out = saved[nl]
         g = grads[nl]
         if g is None:
@@ -90,7 +91,7 @@ class NLayerDiscriminator(BaseNetwork):
         d = self.lay[nl].dgrad(g, xin.shape, aux=gprev, epi=EPI_ADD if gprev is not None else EPI_STORE)
         for n in reversed(range(1, nl)):
             xin, c, s, f = saved[n]
-            dc, _ = ops.in_bwd(d, c, self.chans[n], s, act=ACT_LRELU, slope=LRELU)
+            dc = ops.in_bwd(d, c, self.chans[n], s, act=ACT_LRELU, slope=LRELU)
             if need_wgrad:
                 self.lay[n].wgrad(xin, dc)
             gprev = grads[n - 1]

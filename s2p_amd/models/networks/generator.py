@@ -260,25 +260,22 @@ class S2PGenerator(BaseNetwork):
         for i in reversed(range(self.n_down)):
             xin, u, s, a = ctx["dec"][i]
             cc = u.shape[3]
-            du, _ = ops.in_bwd(dx, u, cc, s, act=ACT_RELU)
+            du = ops.in_bwd(dx, u, cc, s, act=ACT_RELU)
             L[f"up{i}"].wgrad(xin, du)
             dx = L[f"up{i}"].dgrad(du, xin.shape)
         gb_all, st_all = ctx["gb_all"], ctx["st_all"]
         dgb_all = torch.empty_like(gb_all)
-        dst_all = torch.empty_like(st_all)
+        dst_all = torch.empty_like(st_all)                              # [N, 12*2C]: filled by the 12 MAT backward passes
         N = st_all.shape[0]
-        dst_v = dst_all.view(N, -1, 2, C)                               # [N, 12, {gamma,beta}, C]
         for b in reversed(range(self.n_blocks)):
             x, sA, nA, c0, sB, nB = ctx["blocks"][b]
             o0, o1 = (2 * b) * 2 * C, (2 * b + 1) * 2 * C
             L[f"b{b}c1"].wgrad(nB, dx)
             d_nB = L[f"b{b}c1"].dgrad(dx, nB.shape)
-            d_c0, sums = ops.in_bwd(d_nB, c0, C, sB, gb_all, o1, st_all, o1, ACT_LRELU, LRELU, dgb_all, o1)
-            dst_v[:, 2 * b + 1].copy_(sums[:, :, 2:4].permute(0, 2, 1))
+            d_c0 = ops.in_bwd(d_nB, c0, C, sB, gb_all, o1, st_all, o1, ACT_LRELU, LRELU, dgb_all, o1, dst_all, o1)
             L[f"b{b}c0"].wgrad(nA, d_c0)
             d_nA = L[f"b{b}c0"].dgrad(d_c0, nA.shape)
-            d_xb, sums = ops.in_bwd(d_nA, x, C, sA, gb_all, o0, st_all, o0, ACT_LRELU, LRELU, dgb_all, o0)
-            dst_v[:, 2 * b].copy_(sums[:, :, 2:4].permute(0, 2, 1))
+            d_xb = ops.in_bwd(d_nA, x, C, sA, gb_all, o0, st_all, o0, ACT_LRELU, LRELU, dgb_all, o0, dst_all, o0)
             dx = ops.add(dx, d_xb, out=d_xb)
         # image-conditioning branch (batched)
         actv, seg = ctx["actv"], ctx["seg"]
@@ -303,11 +300,11 @@ class S2PGenerator(BaseNetwork):
         # encoder
         for i in reversed(range(self.n_down)):
             xin, x, s, a = ctx["enc"][i + 1]
-            dxe, _ = ops.in_bwd(dx, x, x.shape[3], s, act=ACT_RELU)
+            dxe = ops.in_bwd(dx, x, x.shape[3], s, act=ACT_RELU)
             L[f"down{i}"].wgrad(xin, dxe)
             dx = L[f"down{i}"].dgrad(dxe, xin.shape)
         img, x, s, a = ctx["enc"][0]
-        dxe, _ = ops.in_bwd(dx, x, self.ngf, s, act=ACT_RELU)
+        dxe = ops.in_bwd(dx, x, self.ngf, s, act=ACT_RELU)
         L["stem"].wgrad(img, dxe)
         main.wait_stream(side)
 

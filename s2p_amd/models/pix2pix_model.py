@@ -52,7 +52,10 @@ class Pix2PixModel(nn.Module):
         self.device = torch.device("cuda", opt.gpu_ids[0])
         torch.cuda.set_device(self.device)
         self.compute_dtype = torch.bfloat16 if opt.precision == "bf16" else torch.float32
-        self.assume_unit_loss_grad = True       # trainers call sum(losses).backward(): upstream grads are exactly 1
+        # False (default): the loss nodes scale their gradient seeds by whatever upstream gradient autograd hands them
+        # (loss weights, .mean() over several terms, ...).  Pix2PixTrainer sets it to True because its
+        # `sum(losses.values()).mean().backward()` passes exactly 1 to every term, which saves ~12 tiny launches a step.
+        self.assume_unit_loss_grad = False
         self.netG, self.netD, self.vgg = self.initialize_networks(opt)
 
     # ---- construction / checkpoint I/O ---------------------------------------------------------------------
@@ -69,7 +72,8 @@ class Pix2PixModel(nn.Module):
             path = self.ckpt_path(opt.which_epoch)
             if os.path.exists(path):
                 ckpt = torch.load(path, map_location="cpu")
-            elif not getattr(opt, "random_init", False) and not opt.isTrain:
+            elif not getattr(opt, "random_init", False):
+                # also for --continue_train: silently restarting from random weights would overwrite the run's files
                 raise FileNotFoundError("%s not found (README: put <env_type>_<epoch>.pth under --checkpoints_dir), "
                                         "or pass --random_init" % path)
         if ckpt is not None:
@@ -92,7 +96,8 @@ class Pix2PixModel(nn.Module):
     def save(self, epoch):
         os.makedirs(self.opt.checkpoints_dir, exist_ok=True)
         ck = dict(netG=self.netG.export_state_dict(), epoch=epoch, env_type=self.opt.env_type,
-                  state_dim=self.opt.state_dim)
+                  state_dim=self.opt.state_dim, epochs_done=getattr(self, "epochs_done", 0),
+                  iters_done=getattr(self, "iters_done", 0))
         if self.netD is not None:
             ck["netD"] = self.netD.export_state_dict()
         opts = getattr(self, "_optimizers", None)

@@ -14,28 +14,6 @@ from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, EPI_ADD, EPI_MUL_ACT
 
 IN_EPS = 1e-5
 
-# Zero arena: the reductions (IN moments, backward sums) accumulate with atomics into zero-initialised fp32 buffers.
-# Instead of ~90 tiny memsets per step, each network pass zeroes ONE slab and hands out views of it.
-_ARENA = None
-
-
-def arena_begin(device, nfloats=1 << 21):
-    global _ARENA
-    _ARENA = [torch.zeros(nfloats, dtype=torch.float32, device=device), 0]
-
-
-def zeros_f32(shape, device):
-    global _ARENA
-    n = 1
-    for d in shape:
-        n *= d
-    if _ARENA is not None and _ARENA[0].device == device and _ARENA[1] + n <= _ARENA[0].numel():
-        off = _ARENA[1]
-        _ARENA[1] = off + ((n + 3) // 4) * 4
-        return _ARENA[0][off:off + n].view(shape)
-    return torch.zeros(shape, dtype=torch.float32, device=device)
-
-
 # Optional in-situ profiler used by bench.py's roofline leg: when PROFILE is a list, every MFMA conv launch is
 # bracketed by two events on the launch stream and logged with its algorithmic FLOPs (2*MACs, un-padded channels).
 PROFILE = None
@@ -175,8 +153,10 @@ def channel_sum(dy, C, db):
 
 
 def in_stats(x, C):
+    """Per-(n,c) InstanceNorm statistics: an opaque buffer of partial moments (include/s2p_hip.h) consumed by
+    in_apply_fwd / in_bwd with the same x shape."""
     N, H, W, xp = x.shape
-    stats = zeros_f32((N, C, 2), x.device)
+    stats = torch.empty(lib().s2p_in_stats_floats(N, H * W, C), dtype=torch.float32, device=x.device)
     pr = _ProfNorm("norm_stats", x, C, N * H * W * C * x.element_size(), False)
     check(lib().s2p_in_stats(dtype_id(x.dtype), ptr(x), N, H * W, C, xp, IN_EPS, ptr(stats), stream()), "s2p_in_stats")
     pr.done()
@@ -203,11 +183,12 @@ def in_apply_fwd(x, C, stats, gb=None, gb_off=0, gb_st=None, st_off=0, act=ACT_N
     return y
 
 
-def in_bwd(da, x, C, stats, gb=None, gb_off=0, gb_st=None, st_off=0, act=ACT_NONE, slope=0.2, dgb=None, dgb_off=0):
-    """Backward of in_apply_fwd.  Returns (dx, sums[N,C,4]); writes d(gamma_img|beta_img) into dgb at dgb_off.
-    sums[...,2] / sums[...,3] are d(gamma_st) / d(beta_st)."""
+def in_bwd(da, x, C, stats, gb=None, gb_off=0, gb_st=None, st_off=0, act=ACT_NONE, slope=0.2, dgb=None, dgb_off=0,
+           dgb_st=None, dst_off=0):
+    """Backward of in_apply_fwd.  Returns dx; writes d(gamma_img|beta_img) into dgb at channel offset dgb_off and
+    d(gamma_st|beta_st) into the fp32 [N, pitch] tensor dgb_st at column offset dst_off (layout of gb_st)."""
     N, H, W, xp = x.shape
-    sums = zeros_f32((N, C, 4), x.device)
+    sums = torch.empty(lib().s2p_in_bwd_sums_floats(N, H * W, C), dtype=torch.float32, device=x.device)
     gbp, gb_pitch, stp, st_pitch = _gb_args(gb, gb_off, gb_st, st_off)
     dt = dtype_id(x.dtype)
     el = N * H * W * C * x.element_size()
@@ -217,11 +198,14 @@ def in_bwd(da, x, C, stats, gb=None, gb_off=0, gb_st=None, st_off=0, act=ACT_NON
                                   st_pitch, act, slope, IN_EPS, ptr(sums), stream()), "s2p_in_bwd_reduce")
     dx = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
     dgbp = dgb.data_ptr() + dgb_off * dgb.element_size() if dgb is not None else None
+    dstp = dgb_st.data_ptr() + dst_off * 4 if dgb_st is not None else None
+    _ = ptr(dgb), ptr(dgb_st)
     check(lib().s2p_in_bwd_apply(dt, ptr(da), da.shape[3], ptr(x), N, H * W, C, xp, ptr(stats), gbp, gb_pitch, stp,
                                  st_pitch, act, slope, IN_EPS, ptr(sums), ptr(dx), C, dgbp,
-                                 dgb.shape[3] if dgb is not None else 0, stream()), "s2p_in_bwd_apply")
+                                 dgb.shape[3] if dgb is not None else 0, dstp,
+                                 dgb_st.shape[1] if dgb_st is not None else 0, stream()), "s2p_in_bwd_apply")
     pr.done()
-    return dx, sums
+    return dx
 
 
 def posenc(state, L, pitch):

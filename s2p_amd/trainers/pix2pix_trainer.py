@@ -14,6 +14,8 @@ class Pix2PixTrainer:
         self.opt = opt
         self.pix2pix_model = Pix2PixModel(opt)
         self.pix2pix_model_on_one_gpu = self.pix2pix_model
+        # both steps below call sum(losses).mean().backward(): every loss term's upstream gradient is exactly 1
+        self.pix2pix_model.assume_unit_loss_grad = True
         self.generated = None
         self.dp = parallel.DataParallelGroup.from_env()
         if opt.isTrain:
@@ -21,7 +23,13 @@ class Pix2PixTrainer:
             self.dp.broadcast_store(self.pix2pix_model.netD.store)
             self.optimizer_G, self.optimizer_D = self.pix2pix_model.create_optimizers(opt)
             self.optimizer_G.grad_scale = self.optimizer_D.grad_scale = 1.0 / self.dp.world_size
-            self.old_lr = opt.lr
+            # resume (--continue_train): the schedule continues from the restored optimizer lr and epoch counter
+            ck = self.pix2pix_model._resume
+            self.first_epoch = int(ck.get("epochs_done", 0)) + 1 if ck is not None else 1
+            self.pix2pix_model.epochs_done = self.first_epoch - 1
+            self.pix2pix_model.iters_done = int(ck.get("iters_done", 0)) if ck is not None else 0
+            g_lr = self.optimizer_G.param_groups[0]["lr"]
+            self.old_lr = g_lr if opt.no_TTUR else g_lr * 2
         self.g_losses, self.d_losses = {}, {}
 
     def run_generator_one_step(self, data):
@@ -52,6 +60,11 @@ class Pix2PixTrainer:
     def save(self, epoch):
         if self.dp.rank == 0:
             self.pix2pix_model.save(epoch)
+
+    def end_of_epoch(self, epoch, iters):
+        """Record progress so that a checkpoint written now resumes at epoch + 1."""
+        self.pix2pix_model.epochs_done = epoch
+        self.pix2pix_model.iters_done = iters
 
     def update_learning_rate(self, epoch):
         opt = self.opt

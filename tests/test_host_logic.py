@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_cabi_library_loads_and_exports_every_declared_symbol():
     L = _lib.lib()
-    assert L.s2p_version() >= 100
+    assert L.s2p_version() >= 101
     header = open(os.path.join(ROOT, "include", "s2p_hip.h")).read()
     declared = set(re.findall(r"\b(s2p_[a-z0-9_]+)\s*\(", header))
     declared -= {"s2p_conv_desc", "s2p_pack_job"}
@@ -46,7 +46,7 @@ def test_netG_s2p_plugin_lookup_and_state_dict_contract():
     netG = networks.define_G(opt)
     shapes = O.generator_param_shapes(O.Spec(state_dim=24))
     sd = netG.state_dict()
-    assert list(sd.keys()).sort() == list(shapes.keys()).sort()
+    assert sorted(sd.keys()) == sorted(shapes.keys())
     for k, shp in shapes.items():
         assert tuple(sd[k].shape) == tuple(shp), k
     netD = networks.define_D(opt)

@@ -1,6 +1,7 @@
-"""Op-level parity of every HIP kernel against torch.nn.functional on CPU fp32.
-Integer/index work (pool routing, layout) must be exact; fp32 kernels within 1e-3 relative (north_star);
-bf16 kernels within a documented looser tolerance against the fp32 result of bf16-rounded inputs."""
+"""Op-level parity of every HIP kernel against torch.nn.functional on CPU.
+Integer/index work (pool routing, layout) must be exact; fp32 kernels (exact-fp32 MFMA path) within 1e-5 of the
+float64 result -- 100x tighter than north_star's 1e-3, so that a kernel that loses precision cannot hide behind
+ReLU-kink arguments at model level; bf16 kernels within 2e-2 of the fp32 result of bf16-rounded inputs."""
 import math
 
 import pytest
@@ -42,7 +43,7 @@ def rel_err(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 
 
-TOL = {torch.float32: 1e-3, torch.bfloat16: 2e-2}
+TOL = {torch.float32: 1e-5, torch.bfloat16: 2e-2}
 
 CONV_CASES = [
     # cin, cout, k, stride, pad, transposed, reflect, H, W, N
@@ -76,17 +77,17 @@ def test_conv_fwd_dgrad_wgrad(hip_device, dtype, case):
     if dtype == torch.bfloat16:      # compare against fp32 math on bf16-rounded operands
         x = x.bfloat16().float(); w = w.bfloat16().float()
     op = 1 if tr else 0
-    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+    xr = x.double().requires_grad_(True); wr = w.double().requires_grad_(True)      # float64 reference
     if tr:
-        y_ref = F.conv_transpose2d(xr, wr, b, stride=s, padding=p, output_padding=op)
+        y_ref = F.conv_transpose2d(xr, wr, b.double(), stride=s, padding=p, output_padding=op)
     elif refl:
-        y_ref = F.conv2d(F.pad(xr, (p, p, p, p), mode="reflect"), wr, b, stride=s)
+        y_ref = F.conv2d(F.pad(xr, (p, p, p, p), mode="reflect"), wr, b.double(), stride=s)
     else:
-        y_ref = F.conv2d(xr, wr, b, stride=s, padding=p)
+        y_ref = F.conv2d(xr, wr, b.double(), stride=s, padding=p)
     dy = torch.randn(y_ref.shape, generator=g)
     if dtype == torch.bfloat16:
         dy = dy.bfloat16().float()
-    y_ref.backward(dy)
+    y_ref.backward(dy.double())
 
     cin_pad, cout_pad = ops.pad_to(cin, ce), ops.pad_to(cout, ce)
     geom = ops.ConvGeom(cin, cout, k, s, p, transposed=tr, reflect=refl, output_padding=op)
@@ -132,8 +133,8 @@ def test_conv_groups_epilogues(hip_device, dtype, gshape):
     b = torch.randn(G * cout, generator=g)
     if dtype == torch.bfloat16:
         x = x.bfloat16().float(); w = w.bfloat16().float()
-    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
-    y_ref = F.leaky_relu(F.conv2d(xr, wr, b, padding=1, groups=G), 0.2)
+    xr = x.double().requires_grad_(True); wr = w.double().requires_grad_(True)       # float64 reference
+    y_ref = F.leaky_relu(F.conv2d(xr, wr, b.double(), padding=1, groups=G), 0.2)
     dy = torch.randn(y_ref.shape, generator=g)
     if dtype == torch.bfloat16:
         dy = dy.bfloat16().float()
@@ -145,7 +146,7 @@ def test_conv_groups_epilogues(hip_device, dtype, gshape):
     torch.cuda.synchronize()
     assert rel_err(nchw(y, G * cout), y_ref.detach()) < TOL[dtype]
     # backward through the fused activation: dpre = dy * lrelu'(y) (s2p_act_bwd), then grouped dgrad / wgrad
-    y_ref.backward(dy)
+    y_ref.backward(dy.double())
     dyd = nhwc(dy, G * cout, dtype, dev)
     dpre = ops.act_bwd(dyd, y, ACT_LRELU, 0.2)
     dx = ops.conv_dgrad(geom, dpre, wb, tuple(xd.shape), cin)
@@ -164,7 +165,7 @@ def test_conv_groups_epilogues(hip_device, dtype, gshape):
         w1 = w1.bfloat16().float()
     wf1 = pack_fwd(w1, G * cin, dtype, dev)
     y1 = ops.conv_fwd(geom1, xd, wf1, None, G * cin, aux=xd, epi=EPI_ADD)
-    assert rel_err(nchw(y1, G * cin), x + F.conv2d(x, w1, padding=1)) < TOL[dtype]
+    assert rel_err(nchw(y1, G * cin), x.double() + F.conv2d(x.double(), w1.double(), padding=1)) < TOL[dtype]
     a = F.relu(x)
     ad = nhwc(a, G * cin, dtype, dev)
     wb1 = pack_bwd(w1, G * cin, G * cin, dtype, dev)
@@ -173,7 +174,7 @@ def test_conv_groups_epilogues(hip_device, dtype, gshape):
         dy1 = dy1.bfloat16().float()
     dxm = ops.conv_dgrad(geom1, nhwc(dy1, G * cin, dtype, dev), wb1, tuple(xd.shape), G * cin, aux=ad,
                          epi=EPI_MUL_ACTGRAD, aux_act=ACT_RELU)
-    ref = F.conv_transpose2d(dy1, w1, padding=1) * (a > 0).float()
+    ref = F.conv_transpose2d(dy1.double(), w1.double(), padding=1) * (a > 0).double()
     assert rel_err(nchw(dxm, G * cin), ref) < TOL[dtype]
 
 
@@ -190,14 +191,14 @@ def test_instance_norm_mat(hip_device, dtype, modulated):
     da = torch.randn(N, C, H, W, generator=g)
     if dtype == torch.bfloat16:
         x, gam, bet, da = [t.bfloat16().float() for t in (x, gam, bet, da)]
-    xr, gr, br, sr = [t.clone().requires_grad_(True) for t in (x, gam, bet, st)]
+    xr, gr, br, sr = [t.double().requires_grad_(True) for t in (x, gam, bet, st)]       # float64 reference
     if modulated:
         y_ref = F.leaky_relu(F.instance_norm(xr, eps=1e-5) * (1 + gr + sr[:, :C, None, None]) + br + sr[:, C:, None, None], 0.2)
         act = ACT_LRELU
     else:
         y_ref = F.relu(F.instance_norm(xr, eps=1e-5))
         act = ACT_RELU
-    y_ref.backward(da)
+    y_ref.backward(da.double())
     xd = nhwc(x, C, dtype, dev)
     gb = torch.cat([nhwc(gam, C, dtype, dev), nhwc(bet, C, dtype, dev)], 3).contiguous() if modulated else None
     std = st.to(dev) if modulated else None
@@ -207,14 +208,42 @@ def test_instance_norm_mat(hip_device, dtype, modulated):
     tol = TOL[dtype]
     assert rel_err(nchw(y, C), y_ref.detach()) < tol
     dgb = torch.empty_like(gb) if modulated else None
-    dx, sums = ops.in_bwd(nhwc(da, C, dtype, dev), xd, C, stats, gb, 0, std, 0, act, 0.2, dgb, 0)
+    dst = torch.full((N, 2 * C + 8), 7.0, device=dev) if modulated else None       # state-affine gradient, written at column 4
+    dx = ops.in_bwd(nhwc(da, C, dtype, dev), xd, C, stats, gb, 0, std, 0, act, 0.2, dgb, 0, dst, 4)
     torch.cuda.synchronize()
     assert rel_err(nchw(dx, C), xr.grad) < tol * 2
     if modulated:
         assert rel_err(nchw(dgb, C), gr.grad) < tol
         assert rel_err(nchw(dgb[..., C:], C), br.grad) < tol
-        dst = torch.cat([sums[:, :, 2], sums[:, :, 3]], 1).cpu()
-        assert rel_err(dst, sr.grad) < tol
+        assert rel_err(dst[:, 4:4 + 2 * C].cpu(), sr.grad) < tol
+        assert float(dst[:, :4].min()) == 7.0 and float(dst[:, 4 + 2 * C:].min()) == 7.0      # nothing else touched
+    # no atomics anywhere in the norm kernels: a second run is bitwise identical
+    stats2 = ops.in_stats(xd, C)
+    y2 = ops.in_apply_fwd(xd, C, stats2, gb, 0, std, 0, act, 0.2)
+    dx2 = ops.in_bwd(nhwc(da, C, dtype, dev), xd, C, stats2, gb, 0, std, 0, act, 0.2, dgb, 0, dst, 4)
+    assert torch.equal(stats, stats2) and torch.equal(y, y2) and torch.equal(dx, dx2)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 21, 21), (1, 64, 84, 84), (3, 68, 9, 7)])
+def test_instance_norm_large_mean(hip_device, shape):
+    """|mean| / std = 1e3 (a near-constant, strongly biased channel): single-pass raw moments E[x^2] - E[x]^2 lose all
+    digits here; the pivot-shifted partial moments + Chan merge must not.  fp32, against float64, 1e-3 (the input's own
+    fp32 quantisation at 1e3 is 6e-5 of a standard deviation)."""
+    dev = hip_device
+    g = torch.Generator().manual_seed(17)
+    N, C, H, W = shape
+    x = torch.randn(N, C, H, W, generator=g) + 1000.0 * torch.sign(torch.randn(1, C, 1, 1, generator=g))
+    da = torch.randn(N, C, H, W, generator=g)
+    xr = x.double().requires_grad_(True)
+    y_ref = F.leaky_relu(F.instance_norm(xr, eps=1e-5), 0.2)
+    y_ref.backward(da.double())
+    xd = nhwc(x, C, torch.float32, dev)
+    stats = ops.in_stats(xd, C)
+    y = ops.in_apply_fwd(xd, C, stats, act=ACT_LRELU, slope=0.2)
+    dx = ops.in_bwd(nhwc(da, C, torch.float32, dev), xd, C, stats, act=ACT_LRELU, slope=0.2)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(y, C), y_ref.detach()) < 1e-3
+    assert rel_err(nchw(dx, C), xr.grad) < 2e-3
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -1,6 +1,15 @@
 """Model-level parity on the GPU: the HIP generator / discriminator / loss path (called through the C ABI) against
 the CPU oracle (oracle/s2p_oracle.py) on identical seeded inputs and weights.
-fp32 path: 1e-3 relative (north_star).  bf16 path: looser, documented tolerance against the fp32 oracle."""
+
+How gradients are compared.  ReLU / LeakyReLU / max-pool / |.| make the gradient a discontinuous function of the
+activations: ONE pre-activation that rounds to the other side of 0 (|x| ~ 1e-7 in fp32) changes every upstream
+parameter gradient by ~1e-3 -- in the torch-fp32 oracle just as in the HIP path -- so a plain comparison cannot tell a
+rounding coin-flip from an imprecise kernel.  The tests therefore (1) read the branches the HIP forward actually took
+from its saved activations, (2) count how many differ from the float64 oracle's own branches (a forward-precision
+check: a handful out of millions), and (3) run the float64 oracle WITH those branches (`masks=`), which makes the
+network a smooth function: every HIP parameter gradient must then match to rounding (fp32 path: 1e-4 here, measured
+~3e-6; the op-level tests bound each kernel at 1e-5).  The bf16 path is judged the same way at bf16 tolerances.
+fp32 forward: 1e-5 relative L2 (north_star asks 1e-3)."""
 import os
 
 import pytest
@@ -17,10 +26,14 @@ def rel(a, b):
     return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-12))
 
 
-def grad_errors(named_hip, ref64, ref32=None, floor_frac=1e-3):
+def rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-300))
+
+
+def grad_errors(named_hip, ref64, floor_frac=0.05):
     """Per-parameter relative L2 error of the HIP gradients against the float64 oracle.  Gradients that are
-    structurally zero (e.g. a conv bias in front of an InstanceNorm) are compared against a floor tied to the
-    typical gradient magnitude instead of their own (rounding-noise) norm."""
+    structurally zero (a conv bias in front of an InstanceNorm: exactly 0 in exact arithmetic, rounding noise in any
+    finite precision) are compared against a floor tied to the typical gradient magnitude, not their own norm."""
     rms = {k: float(v.grad.double().pow(2).mean().sqrt()) for k, v in ref64.items()}
     typical = sorted(rms.values())[len(rms) // 2]
     out = {}
@@ -28,24 +41,16 @@ def grad_errors(named_hip, ref64, ref32=None, floor_frac=1e-3):
         b = v.grad.double().flatten()
         a = named_hip[k].grad.detach().cpu().double().flatten()
         floor = floor_frac * typical * b.numel() ** 0.5
-        e_hip = float((a - b).norm() / (b.norm() + floor))
-        e_32 = None
-        if ref32 is not None:
-            e_32 = float((ref32[k].grad.double().flatten() - b).norm() / (b.norm() + floor))
-        out[k] = (e_hip, e_32)
+        out[k] = float((a - b).norm() / (b.norm() + floor))
     return out
 
 
-def check_grads(errs, gtol, frac_exact=None, exact_tol=1e-4):
-    """ReLU / LeakyReLU kinks make the gradient a discontinuous function of the activations: one element whose
-    pre-activation rounds to the other side of 0 (fp32 vs fp64, or bf16 vs fp32) changes every upstream gradient by
-    an isolated 3x3 footprint (measured: tests/tools/diag4.py), i.e. ~1e-3 relative L2 in fp32.  So: every parameter
-    within `gtol`, and (fp32) a fraction of the parameters -- those with no flipped element upstream -- exact."""
-    for k, (e, _) in errs.items():
-        assert e < gtol, (k, e, errs[k])
-    if frac_exact is not None:
-        n_exact = sum(1 for e, _ in errs.values() if e < exact_tol)
-        assert n_exact >= frac_exact * len(errs), (n_exact, len(errs))
+def check_grads(errs, gtol, what):
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    med = sorted(errs.values())[len(errs) // 2]
+    print(f"{what}: worst grad rel-L2 {[(k, '%.2e' % e) for k, e in worst]} median {med:.2e} (tol {gtol:g})")
+    for k, e in errs.items():
+        assert e < gtol, (what, k, e)
 
 
 def to64(params):
@@ -87,28 +92,113 @@ def build(precision, tmp_path, extra=(), env="cheetah"):
     return opt, model, spec, pg, pd, pv
 
 
-@pytest.mark.parametrize("precision,tol,gtol,frac", [("fp32", 1e-3, 1e-2, 0.2), ("bf16", 6e-2, 0.3, None)])
-def test_generator_forward_backward(hip_device, tmp_path, precision, tol, gtol, frac):
+# ---- branches the HIP forward took, read from the activations its autograd nodes saved -------------------------------
+def _nchw(t, C):
+    return t[..., :C].float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def generator_masks(net, c):
+    """c: the ctx dict of _GeneratorNode (fwd_nhwc's saved activations)."""
+    m = {}
+    names = ["stem"] + [f"down{i}" for i in range(net.n_down)]
+    for nm, (_, _, _, a) in zip(names, c["enc"]):
+        m[nm] = _nchw(a, a.shape[3]) > 0
+    C = net.c_mid
+    for b, (_, _, nA, _, _, nB) in enumerate(c["blocks"]):
+        m[f"blocks.{b}.norm_0"] = _nchw(nA, C) > 0
+        m[f"blocks.{b}.norm_1"] = _nchw(nB, C) > 0
+    for i, (_, _, _, x) in enumerate(c["dec"]):
+        m[f"up{i}"] = _nchw(x, x.shape[3]) > 0
+    for i in range(net.n_mlp):
+        h = c["hs"][i + 1]
+        m[f"state_map.fc{i}"] = h.reshape(h.shape[0], -1).float().cpu() > 0
+    return m
+
+
+def discriminator_masks(netD, dctx, N, with_feat_l1):
+    m = {}
+    for k, (d, (_, saved)) in enumerate(zip(netD.subnets(), dctx)):
+        nl = d.n_layers
+        for n in range(nl):
+            f = _nchw(saved[n][3], d.chans[n])
+            m[f"D{k}.model{n}"] = f > 0
+            if with_feat_l1:
+                m[f"l1.feat{k}.{n}"] = torch.sign(f[:N] - f[N:])
+        logit = _nchw(saved[nl][3], 1)
+        m[f"hinge.fake{k}"] = (1.0 + logit[:N]) > 0
+        m[f"hinge.real{k}"] = (1.0 - logit[N:]) > 0
+    return m
+
+
+def vgg_masks(acts, N):
+    from s2p_amd.models.networks.loss import VGG_TAPS
+    m = {}
+    npool, ntap = 0, 0
+    for kind, name, hin, o in acts:
+        if kind == "P":
+            x = _nchw(hin, hin.shape[3])
+            B, C, H, W = x.shape
+            Ho, Wo = H // 2, W // 2
+            win = x[:, :, :Ho * 2, :Wo * 2].reshape(B, C, Ho, 2, Wo, 2).permute(0, 1, 2, 4, 3, 5).reshape(B, C, Ho, Wo, 4)
+            m[f"vgg.pool{npool}"] = win.argmax(4)          # first maximum, as s2p_maxpool2x2_bwd routes it
+            npool += 1
+        else:
+            f = _nchw(o, o.shape[3])
+            m[f"vgg.{name}"] = f > 0
+            if name in VGG_TAPS:
+                m[f"l1.vgg{ntap}"] = torch.sign(f[:N] - f[N:])
+                ntap += 1
+    both = _nchw(acts[0][2], 3)
+    m["l1.pix"] = torch.sign(both[:N] - both[N:])
+    return m
+
+
+def count_flips(masks, trace64):
+    """Branches of the HIP forward that differ from the float64 oracle's own (pre-activation sign)."""
+    n, tot = 0, 0
+    for k, v in trace64.items():
+        if k in masks and masks[k].dtype == torch.bool and v.shape == masks[k].shape:
+            n += int((masks[k] != (v > 0)).sum())
+            tot += v.numel()
+    return n, tot
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision,tol,gtol,max_flips", [("fp32", 1e-5, 1e-4, 24), ("bf16", 3e-2, 6e-2, None)])
+def test_generator_forward_backward(hip_device, tmp_path, precision, tol, gtol, max_flips):
     opt, model, spec, pg, pd, pv = build(precision, tmp_path)
     prev, state, real = make_inputs(2, 84, 84, 17)
     y = model.netG(prev.cuda(), state.cuda())
-    for v in pg.values():
-        v.requires_grad_(True)
-    y_ref = O.generator_forward(pg, prev, state, spec)
-    assert y.shape == y_ref.shape
-    assert rel(y.detach().cpu(), y_ref.detach()) < tol
-    # backward: loss = sum(out * r); gradients judged against the float64 oracle
-    r = torch.randn(y_ref.shape, generator=torch.Generator().manual_seed(5))
+    node = y.grad_fn.next_functions[0][0]                     # _GeneratorNode's backward object holds the saved ctx
+    masks = generator_masks(model.netG, node.c)
+    pg64 = to64(pg)
+    tr = {}
+    y64 = O.generator_forward(pg64, prev.double(), state.double(), spec, trace=tr)
+    assert y.shape == y64.shape
+    e_l2, e_max = rel_l2(y.detach().cpu(), y64.detach()), rel(y.detach().cpu(), y64.detach())
+    flips, total = count_flips(masks, tr)
+    print(f"{precision}: forward rel-L2 {e_l2:.2e} max {e_max:.2e}; {flips} of {total} activation branches differ from float64")
+    assert e_l2 < tol and e_max < 4 * tol
+    if max_flips is not None:
+        assert flips <= max_flips
+    # backward: loss = sum(out * r); float64 oracle run with the branches the HIP forward took
+    r = torch.randn(y64.shape, generator=torch.Generator().manual_seed(5))
     model.netG.store.zero_grad()
     (y * r.cuda()).sum().backward()
-    (y_ref * r).sum().backward()
-    pg64 = to64(pg)
-    (O.generator_forward(pg64, prev.double(), state.double(), spec) * r.double()).sum().backward()
+    pg64m = to64(pg)
+    (O.generator_forward(pg64m, prev.double(), state.double(), spec, masks=masks) * r.double()).sum().backward()
     torch.cuda.synchronize()
-    errs = grad_errors(dict(model.netG.named_parameters()), pg64, pg, 1e-3 if precision == "fp32" else 5e-2)
-    worst = sorted(errs.items(), key=lambda kv: -kv[1][0])[:5]
-    print("worst grad rel-L2 errors (hip, fp32-oracle) vs fp64:", precision, worst)
-    check_grads(errs, gtol, frac)
+    check_grads(grad_errors(dict(model.netG.named_parameters()), pg64m), gtol, f"G {precision}")
+
+
+def test_generator_forward_is_bitwise_reproducible(hip_device, tmp_path):
+    """No atomics on the bf16 generator forward path (IN statistics are merged in a fixed order): two runs agree bit for bit."""
+    opt, model, spec, pg, pd, pv = build("bf16", tmp_path)
+    prev, state, real = make_inputs(2, 84, 84, 17)
+    with torch.no_grad():
+        a = model.netG(prev.cuda(), state.cuda())
+        b = model.netG(prev.cuda(), state.cuda())
+    assert torch.equal(a, b)
 
 
 def test_walker_state_dim_forward(hip_device, tmp_path):
@@ -118,78 +208,126 @@ def test_walker_state_dim_forward(hip_device, tmp_path):
     prev, state, real = make_inputs(3, 84, 84, 24, seed=9)
     with torch.no_grad():
         y = model.netG(prev.cuda(), state.cuda())
-        y_ref = O.generator_forward(pg, prev, state, spec)
+        y_ref = O.generator_forward({k: v.double() for k, v in pg.items()}, prev.double(), state.double(), spec)
     assert y.shape == y_ref.shape == (3, 3, 84, 84)
-    assert rel(y.cpu(), y_ref) < 1e-3
+    assert rel_l2(y.cpu(), y_ref) < 1e-5
+
+
+@pytest.mark.parametrize("env,S", [("cheetah", 17), ("walker", 24)])
+def test_full_batch_forward_fp32(hip_device, tmp_path, env, S):
+    """BASELINE.json configs[1] (and the configs[3] environment): generator forward at the full batch of 64, fp32, against
+    the float64 oracle on 4 of the 64 samples (every op of G is per-sample, so the oracle need not run all 64)."""
+    opt, model, spec, pg, pd, pv = build("fp32", tmp_path, extra=["--batchSize", "64"], env=env)
+    prev, state, real = make_inputs(64, 84, 84, S, seed=41)
+    with torch.no_grad():
+        y = model.netG(prev.cuda(), state.cuda()).cpu()
+    pick = [0, 21, 42, 63]
+    p64 = {k: v.double() for k, v in pg.items()}
+    y_ref = O.generator_forward(p64, prev[pick].double(), state[pick].double(), spec)
+    assert y.shape == (64, 3, 84, 84)
+    assert rel_l2(y[pick], y_ref) < 1e-5 and rel(y[pick], y_ref) < 1e-3
 
 
 @pytest.mark.parametrize("N,S", [(1, 100), (3, 44)])
 def test_edge_shapes_generator_and_discriminator_features(hip_device, tmp_path, N, S):
     """Batch 1 at 100x100 (the dataset's native frame size, odd 25x25 bottleneck, odd D feature maps 51/26/14/15/16) and a
     small odd batch at 44x44 (11x11 bottleneck: tiles spanning several images): generator output and EVERY multiscale
-    discriminator feature map against the oracle, fp32, 1e-3."""
+    discriminator feature map against the float64 oracle, fp32."""
     opt, model, spec, pg, pd, pv = build("fp32", tmp_path)
     prev, state, real = make_inputs(N, S, S, 17, seed=21)
     with torch.no_grad():
         y = model.netG(prev.cuda(), state.cuda())
-        y_ref = O.generator_forward(pg, prev, state, spec)
-        assert y.shape == y_ref.shape and rel(y.cpu(), y_ref) < 1e-3
+        y_ref = O.generator_forward({k: v.double() for k, v in pg.items()}, prev.double(), state.double(), spec)
+        assert y.shape == y_ref.shape and rel_l2(y.cpu(), y_ref) < 1e-5
         x = torch.cat([prev, real], 1)
         feats = model.netD(x.cuda())
-        feats_ref = O.multiscale_discriminator(pd, x, spec)
+        feats_ref = O.multiscale_discriminator({k: v.double() for k, v in pd.items()}, x.double(), spec)
     assert len(feats) == len(feats_ref) == 2
     for fs, fr in zip(feats, feats_ref):
         assert len(fs) == len(fr)
         for f, r_ in zip(fs, fr):
             assert f.shape == r_.shape, (f.shape, r_.shape)
-            assert rel(f.cpu(), r_) < 1e-3
+            assert rel_l2(f.cpu(), r_) < 1e-5
 
 
-@pytest.mark.parametrize("precision,tol,gtol", [("fp32", 2e-3, 2e-2), ("bf16", 8e-2, 0.7)])
-def test_train_step_losses_and_grads(hip_device, tmp_path, precision, tol, gtol):
+@pytest.mark.parametrize("precision,ltol,gtol,dgtol", [("fp32", 1e-4, 1e-4, 1e-4), ("bf16", 3e-2, 8e-2, 8e-2)])
+def test_train_step_losses_and_grads(hip_device, tmp_path, precision, ltol, gtol, dgtol):
+    """One G step and one D step (hinge GAN + feature matching + VGG + L1): every loss value and every parameter gradient
+    against the float64 oracle run with the branches (ReLU / LeakyReLU / max-pool / |.| / hinge) the HIP step took."""
     opt, model, spec, pg, pd, pv = build(precision, tmp_path)
     spec.lambda_feat, spec.lambda_vgg, spec.lambda_l1 = opt.lambda_feat, opt.lambda_vgg, opt.lambda_l1
     prev, state, real = make_inputs(2, 84, 84, 17, seed=3)
+    N = 2
     data = dict(prev_image=prev, state=state, image=real)
+    d64 = lambda p: {k: v.double() for k, v in p.items()}  # noqa: E731
     # ---- generator step
     model.netG.store.zero_grad()
     g_losses, fake = model(data, mode="generator")
+    lnode, gnode = g_losses["GAN"].grad_fn, fake.grad_fn
+    masks = generator_masks(model.netG, gnode.c)
+    masks.update(discriminator_masks(model.netD, lnode.dctx, N, with_feat_l1=True))
+    masks.update(vgg_masks(lnode.vctx, N))
     sum(g_losses.values()).mean().backward()
-    for v in pg.values():
-        v.requires_grad_(True)
-    L_ref, fake_ref = O.generator_losses(pg, pd, pv, prev, state, real, spec)
-    sum(L_ref.values()).backward()
     torch.cuda.synchronize()
-    for k in L_ref:
-        a, b = float(g_losses[k]), float(L_ref[k])
-        assert abs(a - b) <= tol * max(abs(b), 1e-3) * 3, (k, a, b)
-    pg64, pd64, pv64 = to64(pg), {k: v.double() for k, v in pd.items()}, {k: v.double() for k, v in pv.items()}
-    L64, _ = O.generator_losses(pg64, pd64, pv64, prev.double(), state.double(), real.double(), spec)
+    pg64 = to64(pg)
+    L64, _ = O.generator_losses(pg64, d64(pd), d64(pv), prev.double(), state.double(), real.double(), spec, masks=masks)
     sum(L64.values()).backward()
-    errs = grad_errors(dict(model.netG.named_parameters()), pg64, pg, 1e-3 if precision == "fp32" else 5e-2)
-    print("G-step worst grad errors:", precision, sorted(errs.items(), key=lambda kv: -kv[1][0])[:5])
-    check_grads(errs, gtol)
-    # ---- discriminator step
+    for k in L64:
+        a, b = float(g_losses[k]), float(L64[k])
+        print(f"G loss {k}: hip {a:.6f} oracle {b:.6f}")
+        assert abs(a - b) <= ltol * max(abs(b), 1e-2), (k, a, b)
+    check_grads(grad_errors(dict(model.netG.named_parameters()), pg64), gtol, f"G-step {precision}")
+    # ---- discriminator step (the oracle is fed the HIP generator's own fake: the comparison isolates the D path)
     model.netD.store.zero_grad()
     d_losses = model(data, mode="discriminator")
+    dnode = d_losses["D_Fake"].grad_fn
+    dmasks = discriminator_masks(model.netD, dnode.dctx, N, with_feat_l1=False)
+    fake_hip = _nchw(dnode.dctx[0][0][:N], 6)[:, 3:6].double()
     sum(d_losses.values()).mean().backward()
-    for v in pg.values():
-        v.requires_grad_(False)
-    for v in pd.values():
-        v.requires_grad_(True)
-    D_ref = O.discriminator_losses(pg, pd, prev, state, real, spec)
-    sum(D_ref.values()).backward()
     torch.cuda.synchronize()
-    for k in D_ref:
-        a, b = float(d_losses[k]), float(D_ref[k])
-        assert abs(a - b) <= tol * max(abs(b), 1e-3) * 3, (k, a, b)
     pd64 = to64(pd)
-    D64 = O.discriminator_losses({k: v.detach().double() for k, v in pg.items()}, pd64, prev.double(), state.double(),
-                                 real.double(), spec)
+    D64 = O.discriminator_losses(None, pd64, prev.double(), state.double(), real.double(), spec, masks=dmasks, fake=fake_hip)
     sum(D64.values()).backward()
-    errs = grad_errors(dict(model.netD.named_parameters()), pd64, pd, 1e-3 if precision == "fp32" else 5e-2)
-    print("D-step worst grad errors:", precision, sorted(errs.items(), key=lambda kv: -kv[1][0])[:5])
-    check_grads(errs, gtol)
+    for k in D64:
+        a, b = float(d_losses[k]), float(D64[k])
+        print(f"D loss {k}: hip {a:.6f} oracle {b:.6f}")
+        assert abs(a - b) <= ltol * max(abs(b), 1e-2), (k, a, b)
+    check_grads(grad_errors(dict(model.netD.named_parameters()), pd64), dgtol, f"D-step {precision}")
+
+
+def test_loss_weights_reach_the_gradients(hip_device, tmp_path):
+    """Upstream gradients of the individual loss terms are honoured: (0.5*GAN + 2*VGG + 0*L1 + 1.5*GAN_Feat).backward()
+    (not the trainer's plain sum) against the float64 oracle with the same weights, and a weighted D loss."""
+    opt, model, spec, pg, pd, pv = build("fp32", tmp_path)
+    spec.lambda_feat, spec.lambda_vgg, spec.lambda_l1 = opt.lambda_feat, opt.lambda_vgg, opt.lambda_l1
+    prev, state, real = make_inputs(2, 84, 84, 17, seed=13)
+    data = dict(prev_image=prev, state=state, image=real)
+    d64 = lambda p: {k: v.double() for k, v in p.items()}  # noqa: E731
+    wts = dict(GAN=0.5, GAN_Feat=1.5, VGG=2.0, L1=0.0)
+    model.netG.store.zero_grad()
+    g_losses, fake = model(data, mode="generator")
+    lnode, gnode = g_losses["GAN"].grad_fn, fake.grad_fn
+    masks = generator_masks(model.netG, gnode.c)
+    masks.update(discriminator_masks(model.netD, lnode.dctx, 2, with_feat_l1=True))
+    masks.update(vgg_masks(lnode.vctx, 2))
+    sum(wts[k] * v for k, v in g_losses.items()).backward()
+    torch.cuda.synchronize()
+    pg64 = to64(pg)
+    L64, _ = O.generator_losses(pg64, d64(pd), d64(pv), prev.double(), state.double(), real.double(), spec, masks=masks)
+    sum(wts[k] * v for k, v in L64.items()).backward()
+    check_grads(grad_errors(dict(model.netG.named_parameters()), pg64), 1e-4, "weighted G losses")
+    # D step with unequal weights on the two hinge terms
+    model.netD.store.zero_grad()
+    d_losses = model(data, mode="discriminator")
+    dnode = d_losses["D_Fake"].grad_fn
+    dmasks = discriminator_masks(model.netD, dnode.dctx, 2, with_feat_l1=False)
+    fake_hip = _nchw(dnode.dctx[0][0][:2], 6)[:, 3:6].double()
+    (3.0 * d_losses["D_Fake"] + 0.25 * d_losses["D_real"]).backward()
+    torch.cuda.synchronize()
+    pd64 = to64(pd)
+    D64 = O.discriminator_losses(None, pd64, prev.double(), state.double(), real.double(), spec, masks=dmasks, fake=fake_hip)
+    (3.0 * D64["D_Fake"] + 0.25 * D64["D_real"]).backward()
+    check_grads(grad_errors(dict(model.netD.named_parameters()), pd64), 1e-4, "weighted D losses")
 
 
 def test_trainer_steps_and_checkpoint(hip_device, tmp_path):
@@ -218,6 +356,46 @@ def test_trainer_steps_and_checkpoint(hip_device, tmp_path):
     assert torch.equal(ck["netG"]["out.weight"], w1)
 
 
+def test_trainer_step_matches_oracle_adam(hip_device, tmp_path):
+    """One full fp32 trainer G step (losses -> backward -> fused Adam on the flat buffer): the updated master weights against
+    the oracle's gradients (taken with the HIP step's branches) pushed through the oracle's Adam restatement."""
+    from s2p_amd.trainers.pix2pix_trainer import Pix2PixTrainer
+    args = ["--env_type", "cheetah", "--batchSize", "2", "--precision", "fp32", "--gpu_ids", "0",
+            "--checkpoints_dir", str(tmp_path)]
+    opt = TrainOptions().parse(args, quiet=True)
+    tr = Pix2PixTrainer(opt)
+    model = tr.pix2pix_model
+    spec = O.Spec(state_dim=opt.state_dim)
+    spec.lambda_feat, spec.lambda_vgg, spec.lambda_l1 = opt.lambda_feat, opt.lambda_vgg, opt.lambda_l1
+    pg = randomize(O.init_params(O.generator_param_shapes(spec), 1), 11, 1.0)
+    pd = randomize(O.init_params(O.discriminator_param_shapes(spec), 2), 12, 1.0)
+    pv = O.init_params(O.vgg_param_shapes(), 3, kaiming=True)
+    model.netG.load_state_dict(pg); model.netD.load_state_dict(pd); model.vgg.load_state_dict(pv)
+    prev, state, real = make_inputs(2, 84, 84, 17, seed=23)
+    tr.run_generator_one_step(dict(prev_image=prev, state=state, image=real))
+    torch.cuda.synchronize()
+    new = {k: v.detach().cpu().double() for k, v in model.netG.named_parameters()}
+    # oracle: same step with plain float64 branches (Adam's first step is sign-like: m/sqrt(v) = g/|g|, so a gradient that is
+    # right to 1e-4 moves every weight by lr * (1 +- 1e-4); compare the UPDATE, not the weights)
+    d64 = lambda p: {k: v.double() for k, v in p.items()}  # noqa: E731
+    pg64 = to64(pg)
+    L64, _ = O.generator_losses(pg64, d64(pd), d64(pv), prev.double(), state.double(), real.double(), spec)
+    sum(L64.values()).backward()
+    lr = opt.lr / 2 if not opt.no_TTUR else opt.lr
+    b1, b2 = (0.0, 0.9) if not opt.no_TTUR else (opt.beta1, opt.beta2)
+    bad = 0
+    total = 0
+    for k, p0 in pg.items():
+        g = pg64[k].grad
+        p1, _, _ = O.adam_step(p0.double(), g, torch.zeros_like(g), torch.zeros_like(g), 1, lr, b1, b2)
+        upd_ref, upd = p1 - p0.double(), new[k] - p0.double()
+        big = g.abs() > 1e-3 * g.abs().max()              # where the gradient is far from 0 the update is +-lr exactly
+        bad += int(((upd - upd_ref).abs() > 0.02 * lr)[big].sum())
+        total += int(big.sum())
+    print(f"Adam step: {bad} of {total} well-conditioned weights differ from the oracle update by more than 2 % of lr")
+    assert bad <= 1e-4 * total
+
+
 def test_rollout_matches_oracle_and_golden(hip_device, tmp_path):
     """N-step autoregressive generation (config 1/5 path): frames stay on the device in NHWC between steps."""
     import numpy as np
@@ -238,10 +416,10 @@ def test_rollout_matches_oracle_and_golden(hip_device, tmp_path):
     states = torch.stack([state, state * 0.5, -state], 1)
     frames = rollout(model.netG, prev, states).cpu()
     assert frames.shape == (1, 3, 3, 84, 84)
-    assert rel(frames[:, 0], torch.from_numpy(G["fake"])) < 1e-3            # committed golden vector
-    assert rel(frames[:, -1], torch.from_numpy(G["rollout_last"])) < 1e-3
+    assert rel(frames[:, 0], torch.from_numpy(G["fake"])) < 1e-4            # committed golden vector
+    assert rel(frames[:, -1], torch.from_numpy(G["rollout_last"])) < 1e-4
     ref = O.rollout(pg, prev, states, spec)
-    assert rel(frames, ref) < 1e-3
+    assert rel(frames, ref) < 1e-4
 
 
 def test_generator_256x256_bf16_runs_and_matches(hip_device, tmp_path):
@@ -288,6 +466,36 @@ def test_full_size_shard_additivity_bf16(hip_device, tmp_path):
     for full, a, b, name in ((g_full, g_a, g_b, "G"), (d_full, d_a, d_b, "D")):
         ref = 0.5 * (a + b)
         err = float((full - ref).norm() / ref.norm())
-        # bf16 operands + a different tile composition per run: a LeakyReLU input that rounds to the other side of 0 flips a
-        # whole 4x4 footprint of the D gradient (measured: G 1e-2, D 4e-2)
+        print(f"shard additivity {name}: {err:.3e}")
+        # bf16 operands; the IN split geometry depends on the batch, so a LeakyReLU input may round to the other side of 0
+        # and flip a 4x4 footprint of the D gradient (measured: G 1e-2, D 4e-2)
         assert err < (2e-2 if name == "G" else 8e-2), (name, err)
+
+
+def test_simple_test_cli_seq_len_5(hip_device, tmp_path):
+    """BASELINE.json configs[0]: `simple_test.py --env_type=cheetah --dataroot=./datasets --netG=s2p --start_idx=0
+    --seq_len=5 --gpu_ids=0` (README.md:33) end to end on the shipped tiny dataset, random-init weights; the generated
+    frames are checked against the oracle's rollout with the same weights."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import simple_test
+    from s2p_amd.data import S2PDataset
+    from s2p_amd.options.test_options import TestOptions
+    args = ["--env_type=cheetah", "--dataroot=" + os.path.join(root, "datasets"), "--netG=s2p", "--start_idx=0",
+            "--seq_len=5", "--gpu_ids=0", "--random_init", "--precision", "fp32", "--checkpoints_dir", str(tmp_path),
+            "--results_dir", str(tmp_path)]
+    torch.manual_seed(1234)
+    gen = simple_test.main(args)
+    assert gen.shape[0] == 5 and gen.shape[1] == 3 and bool(torch.isfinite(gen).all())
+    assert any(f.endswith((".png", ".npy")) for f in os.listdir(str(tmp_path)))
+    # same weights through the oracle
+    torch.manual_seed(1234)
+    opt = TestOptions().parse(args, quiet=True)
+    model = Pix2PixModel(opt)
+    sd = {k: v.detach().cpu() for k, v in model.netG.export_state_dict().items()}
+    ds = S2PDataset(opt)
+    frames, states = ds.sequence(0, 5)
+    ref = O.rollout(sd, frames[:1], states[1:].unsqueeze(0), O.Spec(state_dim=opt.state_dim))[0]
+    again = simple_test.rollout(model.netG, frames[:1], states[1:].unsqueeze(0))[0].cpu()
+    assert rel(again, ref) < 1e-4

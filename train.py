@@ -16,8 +16,8 @@ def main(args=None):
     trainer = Pix2PixTrainer(opt)
     dl = create_dataloader(opt, trainer.dp.rank, trainer.dp.world_size)
     total_epochs = opt.niter + opt.niter_decay
-    it = 0
-    for epoch in range(1, total_epochs + 1):
+    it = trainer.pix2pix_model.iters_done                 # > 0 when resuming with --continue_train
+    for epoch in range(trainer.first_epoch, total_epochs + 1):
         if hasattr(dl.sampler, "set_epoch"):
             dl.sampler.set_epoch(epoch)
         t0 = time.time()
@@ -30,6 +30,7 @@ def main(args=None):
                 losses = {k: float(v) for k, v in trainer.get_latest_losses().items()}
                 print("(epoch %d, iters %d) " % (epoch, it) + " ".join("%s: %.3f" % kv for kv in losses.items()))
         trainer.update_learning_rate(epoch)
+        trainer.end_of_epoch(epoch, it)
         if trainer.dp.rank == 0:
             print("End of epoch %d / %d \t Time Taken: %d sec" % (epoch, total_epochs, time.time() - t0))
         if epoch % opt.save_epoch_freq == 0 or epoch == total_epochs:
