@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void in_reduce_kernel(const NormArgs a) {
         float M2 = tot[1] - tot[0] * d;
         float* o = (float*)a.stats + STATS_HDR + (((size_t)n * a.C + c) * a.psplit + blockIdx.z) * 2;
         o[0] = cst[0][tid] + d; o[1] = M2 > 0.f ? M2 : 0.f;
-        if (c == 0 && n == 0 && blockIdx.z == 0) { ((int*)a.stats)[0] = a.psplit; ((int*)a.stats)[1] = a.rows_per_split; }
+        if (c == 0 && n == 0 && blockIdx.z == 0) *(i32x4*)a.stats = (i32x4){a.psplit, a.rows_per_split, 0, 0};
       } else {
         float* o = a.sums + (((size_t)n * a.C + c) * a.psplit + blockIdx.z) * 4;
         *(f32x4*)o = (f32x4){tot[0], tot[1], tot[2], tot[3]};

@@ -228,19 +228,20 @@ def test_instance_norm_mat(hip_device, dtype, modulated):
 def test_instance_norm_large_mean(hip_device, shape):
     """|mean| / std = 1e3 (a near-constant, strongly biased channel): single-pass raw moments E[x^2] - E[x]^2 lose all
     digits here; the pivot-shifted partial moments + Chan merge must not.  fp32, against float64, 1e-3 (the input's own
-    fp32 quantisation at 1e3 is 6e-5 of a standard deviation)."""
+    fp32 quantisation at 1e3 is 6e-5 of a standard deviation).  No activation here: with |xhat| known only to ~1e-4 a
+    handful of LeakyReLU branches would differ from float64 and dominate a max-norm comparison of dx."""
     dev = hip_device
     g = torch.Generator().manual_seed(17)
     N, C, H, W = shape
     x = torch.randn(N, C, H, W, generator=g) + 1000.0 * torch.sign(torch.randn(1, C, 1, 1, generator=g))
     da = torch.randn(N, C, H, W, generator=g)
     xr = x.double().requires_grad_(True)
-    y_ref = F.leaky_relu(F.instance_norm(xr, eps=1e-5), 0.2)
+    y_ref = F.instance_norm(xr, eps=1e-5)
     y_ref.backward(da.double())
     xd = nhwc(x, C, torch.float32, dev)
     stats = ops.in_stats(xd, C)
-    y = ops.in_apply_fwd(xd, C, stats, act=ACT_LRELU, slope=0.2)
-    dx = ops.in_bwd(nhwc(da, C, torch.float32, dev), xd, C, stats, act=ACT_LRELU, slope=0.2)
+    y = ops.in_apply_fwd(xd, C, stats, act=ACT_NONE)
+    dx = ops.in_bwd(nhwc(da, C, torch.float32, dev), xd, C, stats, act=ACT_NONE)
     torch.cuda.synchronize()
     assert rel_err(nchw(y, C), y_ref.detach()) < 1e-3
     assert rel_err(nchw(dx, C), xr.grad) < 2e-3
