@@ -84,10 +84,11 @@ _lib = None
 def build(force=False):
     """Compile libs2p_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
     script = os.path.join(_HERE, "csrc", "build.sh")
-    if force and os.path.exists(_SO):
-        os.remove(_SO)
-    subprocess.check_call(["bash", script])
-    return _SO
+    env = dict(os.environ)
+    if force:
+        env["FORCE"] = "1"                 # recompile every .hip even when the shipped .so is newer than the sources
+    subprocess.check_call(["bash", script], env=env)
+    return os.path.join(_HERE, "csrc", "libs2p_hip.so")
 
 
 def lib():

@@ -1,16 +1,22 @@
 #!/bin/bash
-# Build libs2p_hip.so for gfx950 (cross-compiles without a GPU).  Usage: build.sh [extra hipcc flags]
+# Build libs2p_hip.so for gfx950 (cross-compiles without a GPU).
+#   build.sh                 product library (no diagnostics, reads no environment variables)
+#   build.sh diag            libs2p_hip_diag.so with -DS2P_DIAG_BUILD (timing ablations + A/B switches; select it with
+#                            S2P_LIB=.../libs2p_hip_diag.so -- only tools/ do)
+#   FORCE=1 build.sh         rebuild even when the library is newer than every source
 set -e
 cd "$(dirname "$0")"
-OUT=libs2p_hip.so
+OUT=libs2p_hip.so; SUF=""; EXTRA=""
+if [ "$1" = "diag" ]; then OUT=libs2p_hip_diag.so; SUF=".diag"; EXTRA="-DS2P_DIAG_BUILD"; shift; fi
 SRCS="conv_igemm.hip wgrad_igemm.hip norm.hip misc.hip thin_conv.hip metrics.hip"
 newest=$(ls -t $SRCS s2p_common.h ../../include/s2p_hip.h build.sh | head -1)
-if [ -f "$OUT" ] && [ "$OUT" -nt "$newest" ]; then exit 0; fi
-pids=()
+if [ -z "$FORCE" ] && [ -f "$OUT" ] && [ "$OUT" -nt "$newest" ]; then echo "up to date: $(pwd)/$OUT"; exit 0; fi
+pids=(); objs=""
 for s in $SRCS; do
-  hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -c "$s" -o "${s%.hip}.o" "$@" &
+  o="${s%.hip}${SUF}.o"; objs="$objs $o"
+  hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value $EXTRA -c "$s" -o "$o" "$@" &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" conv_igemm.o wgrad_igemm.o norm.o misc.o thin_conv.o metrics.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" $objs
 echo "built $(pwd)/$OUT"

@@ -13,7 +13,6 @@
 // per K step; epilogue goes through LDS so every global store is a full 16-B chunk along the channel axis.
 #include "s2p_common.h"
 #include <type_traits>
-#include <stdlib.h>
 
 #define MAX_TAPS 64
 
@@ -158,7 +157,7 @@ __device__ __forceinline__ void conv_epilogue(const GatherArgs& a, f32x16 (&acc)
         continue;
       }
     }
-    if (a.diag == 6 && c.raw[0] != 0x12345678u) continue;
+    if (S2P_DIAGV(a) == 6 && c.raw[0] != 0x12345678u) continue;
     if (full) *(u32x4*)(yg + go) = c.raw;
     else for (int e = 0; e < CE; ++e) if (co0 + e < a.Cst) yg[go + e] = from_f32<T>(c.get(e));
   }
@@ -640,11 +639,11 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const GatherArgs a) {
   if (nk > 0) issue(0);
   __syncthreads();                                    // hipcc drains vmcnt before the barrier (LDS-DMA in flight)
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk && a.diag != 1) issue((kt + 1) & 1);
+    if (kt + 1 < nk && S2P_DIAGV(a) != 1) issue((kt + 1) & 1);
     const char* base = smem + (kt & 1) * STAGE;
     const char* wrow = base + (wco0 + r) * RS;
     const char* prow = base + (BCO + wpix0 + r) * RS;
-    if (a.diag != 2)
+    if (S2P_DIAGV(a) != 2)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int ch = ((2 * s + h) ^ sw) * 16;
@@ -795,7 +794,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
 
   // one linear pipeline over (slab, tap): weights are always one step ahead; the next slab's halo is prefetched
   // into the other halo buffer during the current slab (DBUF) or loaded behind a barrier at the slab boundary.
-  if (a.diag == 5) return;                              // timing ablation: index set-up only
+  if (S2P_DIAGV(a) == 5) return;                              // timing ablation: index set-up only
   if constexpr (TS > 0 && PIPE && DBUF) {
     // Software-pipelined static-tap form.  The weight stage is split into BK=32 HALF-stages (4 x 8 KiB in the same
     // 32 KiB as two full stages): the DMA of half-step h+3 is issued (inline asm, so the waits can be counted) while
@@ -878,9 +877,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
     if (nhs > 2) { issue_wh(2, wtv[1], 0); S2P_WAIT_VMCNT(2); } else { S2P_WAIT_VMCNT(0); }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (a.diag == 3) return;
+    if (S2P_DIAGV(a) == 3) return;
     unsigned long long st_c0 = 0, st_r0 = 0;
-    if (a.diag == 8) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+    if (S2P_DIAGV(a) == 8) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
     read_frags(std::integral_constant<int, 0>{}, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, hbase);
     int hs = 0;
     for (int slab = 0; slab < nslab; ++slab) {
@@ -924,7 +923,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
         ++hs;
       });
     }
-    if (a.diag == 8) {
+    if (S2P_DIAGV(a) == 8) {
       const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
       if (tid == 0 && g == 0) {
         unsigned long long* o = (unsigned long long*)a.y + (size_t)blockIdx.x * 2;
@@ -935,7 +934,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    if (a.diag == 4) { if (acc[0][0][0] == 12345.678f) ((float*)a.y)[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1]; return; }
+    if (S2P_DIAGV(a) == 4) { if (acc[0][0][0] == 12345.678f) ((float*)a.y)[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1]; return; }
     conv_epilogue<T, BCO, BPIX, TCO, TPIX>(a, acc, smem, rowoff, g, co_base, wco0, wpix0, r, h, tid);
     return;
   } else if constexpr (TS > 0) {
@@ -961,22 +960,22 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
     issue_halo(0, 0);
     issue_w(0, wtv[0] << 16, 0);
     __syncthreads();
-    if (a.diag == 3) return;
+    if (S2P_DIAGV(a) == 3) return;
     unsigned long long st_c0 = 0, st_r0 = 0;
-    if (a.diag == 8) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+    if (S2P_DIAGV(a) == 8) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
     int kt = 0;
     for (int slab = 0; slab < nslab; ++slab) {
       const char* hb = hbase + (DBUF ? (slab & 1) * HALO : 0);
       const bool more_slabs = slab + 1 < nslab;
 #pragma unroll
       for (int t = 0; t < TS; ++t, ++kt) {
-        if (a.diag != 1) {
+        if (S2P_DIAGV(a) != 1) {
           if (t + 1 < TS) issue_w((kt + 1) & 1, wtv[t + 1] << 16, slab * BK);
           else if (more_slabs) issue_w((kt + 1) & 1, wtv[0] << 16, (slab + 1) * BK);
           if (DBUF && t == 0 && more_slabs) issue_halo((slab + 1) & 1, (slab + 1) * BK);
         }
         const char* wrow = wbase + (kt & 1) * WSTAGE + (wco0 + r) * RS;
-        if (a.diag != 2) {
+        if (S2P_DIAGV(a) != 2) {
           bf16x8 af[4][TCO], bf[4][TPIX];
 #pragma unroll
           for (int s4 = 0; s4 < 4; ++s4) {
@@ -1001,7 +1000,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
         __syncthreads();
       }
     }
-    if (a.diag == 8) {
+    if (S2P_DIAGV(a) == 8) {
       const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
       if (tid == 0 && g == 0) {
         unsigned long long* o = (unsigned long long*)a.y + (size_t)blockIdx.x * 2;
@@ -1010,7 +1009,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
       if (acc[0][0][0] == 12345.678f) ((float*)a.y)[7] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1];
       return;
     }
-    if (a.diag == 4) { if (acc[0][0][0] == 12345.678f) ((float*)a.y)[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1]; return; }
+    if (S2P_DIAGV(a) == 4) { if (acc[0][0][0] == 12345.678f) ((float*)a.y)[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1]; return; }
     conv_epilogue<T, BCO, BPIX, TCO, TPIX>(a, acc, smem, rowoff, g, co_base, wco0, wpix0, r, h, tid);
     return;
   }
@@ -1020,12 +1019,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
   issue_halo(0, 0);
   issue_w(0, tw_cur, 0);
   __syncthreads();                                     // hipcc drains vmcnt before the barrier
-  if (a.diag == 3) return;                              // timing ablation: prologue only
+  if (S2P_DIAGV(a) == 3) return;                              // timing ablation: prologue only
   int slab = 0, tap = 0;
   // S2P_DIAG=8 (diagnostic build of the launch, output invalid): stamp shader clock and 100 MHz wall clock around the
   // main loop; the host tool derives the in-kernel clock and cycles per K step (tools/clock_halo.py)
   unsigned long long st_c0 = 0, st_r0 = 0;
-  if (a.diag == 8) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+  if (S2P_DIAGV(a) == 8) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
   for (int kt = 0; kt < nk; ++kt) {
     const int c0 = slab * BK;
     int ntap = tap + 1, nslab_i = slab;
@@ -1033,8 +1032,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
     int n2tap = ntap + 1;
     if (n2tap == a.T) n2tap = 0;
     const int tw_next2 = a.tap[n2tap];
-    if (kt + 1 < nk && a.diag != 1) issue_w((kt + 1) & 1, tw_next, nslab_i * BK);
-    if (DBUF && tap == 0 && slab + 1 < nslab && a.diag != 1) issue_halo((slab + 1) & 1, c0 + BK);
+    if (kt + 1 < nk && S2P_DIAGV(a) != 1) issue_w((kt + 1) & 1, tw_next, nslab_i * BK);
+    if (DBUF && tap == 0 && slab + 1 < nslab && S2P_DIAGV(a) != 1) issue_halo((slab + 1) & 1, c0 + BK);
     const char* hb = hbase + (DBUF ? (slab & 1) * HALO : 0);
     const int ti = tw_cur;
     const int toff = (int)(signed char)(ti & 0xff) * a.Wi + (int)(signed char)((ti >> 8) & 0xff);
@@ -1048,7 +1047,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
       prow[j] = ok ? hb + hp * RS : zrow;
       psw[j] = ok ? (hp >> 1) & 7 : 0;
     }
-    if (a.diag != 2) {
+    if (S2P_DIAGV(a) != 2) {
       // all 16 fragment reads of the step are issued before its first MFMA (the waits become counted lgkmcnt(N)):
       // reading per sub-step exposes the LDS latency four times per step
       bf16x8 af[4][TCO], bf[4][TPIX];
@@ -1080,7 +1079,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
     }
   }
   (void)nk;
-  if (a.diag == 8) {
+  if (S2P_DIAGV(a) == 8) {
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     if (tid == 0 && g == 0) {
       unsigned long long* o = (unsigned long long*)a.y + (size_t)blockIdx.x * 2;
@@ -1089,7 +1088,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
     if (acc[0][0][0] == 12345.678f) ((float*)a.y)[7] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1];
     return;
   }
-  if (a.diag == 4) { if (acc[0][0][0] == 12345.678f) ((float*)a.y)[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1]; return; }
+  if (S2P_DIAGV(a) == 4) { if (acc[0][0][0] == 12345.678f) ((float*)a.y)[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1]; return; }
   conv_epilogue<T, BCO, BPIX, TCO, TPIX>(a, acc, smem, rowoff, g, co_base, wco0, wpix0, r, h, tid);
 }
 
@@ -1098,10 +1097,10 @@ static int launch_fast(GatherArgs& a, int groups, hipStream_t st) {
   a.npix_tiles = cdiv(a.M, BPIX);
   a.nco_tiles = cdiv(a.Cst, BCO);
   dim3 grid(a.npix_tiles * a.nco_tiles, groups);
-  static const int no_dma = getenv("S2P_NO_LDS_DMA") ? 1 : 0;
-  static const int diag = getenv("S2P_DIAG") ? atoi(getenv("S2P_DIAG")) : 0;
+  static const int no_dma = s2p_env_set("S2P_NO_LDS_DMA");
+  static const int diag = s2p_env_int("S2P_DIAG", 0);
   a.diag = diag;
-  static const int no_halo = getenv("S2P_NO_HALO") ? 1 : 0;        // A/B switch: plain LDS-DMA kernel
+  static const int no_halo = s2p_env_set("S2P_NO_HALO");        // A/B switch: plain LDS-DMA kernel
   if constexpr (BCO == 128 && BPIX == 128) {
     if (!no_dma && !no_halo && a.istride == 1 && a.ostride == 1 && a.Qh == a.Hi && a.Qw == a.Wi && a.Ho == a.Qh &&
         a.Wo == a.Qw && a.T >= 4) {
@@ -1113,9 +1112,9 @@ static int launch_fast(GatherArgs& a, int groups, hipStream_t st) {
       }
       a.halo_lo = lo; a.halo_hi = hi;
       const int npos = BPIX + lo + hi;
-      static const int extra_lds = getenv("S2P_HALO_EXTRA_LDS") ? atoi(getenv("S2P_HALO_EXTRA_LDS")) : 0;   // occupancy experiment
-      static const int no_ts = getenv("S2P_NO_STATIC_TAPS") ? 1 : 0;
-      static const int pipe = getenv("S2P_NO_HALO_PIPE") ? 0 : 1;         // A/B switch: software-pipelined variant (default on)
+      static const int extra_lds = s2p_env_int("S2P_HALO_EXTRA_LDS", 0);   // occupancy experiment
+      static const int no_ts = s2p_env_set("S2P_NO_STATIC_TAPS");
+      static const int pipe = (s2p_env_set("S2P_NO_HALO_PIPE") ? 0 : 1);         // A/B switch: software-pipelined variant (default on)
       if (a.T == 9 && !no_ts && pipe && npos <= 176 && a.Cin % 64 == 0) {
         hipLaunchKernelGGL((conv_halo_kernel<176, true, 9, true>), grid, dim3(256), extra_lds, st, a); S2P_CHECK_LAUNCH("conv_halo_kernel"); return 0;
       }
@@ -1185,7 +1184,7 @@ static int run_scatter(const Geo& G, const void* x, const void* w, const float* 
   const int s = G.stride;
   if constexpr (sizeof(T) == 2) {
     // all s*s phases in ONE launch of the LDS-DMA kernel (blockIdx.z = phase) when that kernel applies
-    static const int no_merge = (getenv("S2P_NO_PHASE_MERGE") || getenv("S2P_NO_LDS_DMA")) ? 1 : 0;
+    static const int no_merge = (s2p_env_set("S2P_NO_PHASE_MERGE") || s2p_env_set("S2P_NO_LDS_DMA"));
     const long long xb = (long long)G.N * G.Hi * G.Wi * G.xp * 2, wb = (long long)G.Co * G.w_row * 2;
     if (!no_merge && s * s <= MAX_PHASES && s > 1 && G.Ci % 64 == 0 && xb < (1ll << 31) && wb < (1ll << 31) && G.Cst > 32) {
       GatherArgs a{};
@@ -1197,7 +1196,7 @@ static int run_scatter(const Geo& G, const void* x, const void* w, const float* 
       a.w_row = G.w_row; a.w_gstride = G.w_gstride;
       a.reflect = 0; a.act = act; a.epi = epi; a.slope = slope; a.gact = gact; a.gslope = gslope;
       a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
-      static const int diag = getenv("S2P_DIAG") ? atoi(getenv("S2P_DIAG")) : 0;
+      static const int diag = s2p_env_int("S2P_DIAG", 0);
       a.diag = diag;
       bool ok = true;
       int np = 0, max_npt = 0;

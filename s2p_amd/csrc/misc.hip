@@ -336,7 +336,7 @@ extern "C" int s2p_l1_loss(int dtype, const void* a, const void* b, int64_t coun
   if (!a || !b || !loss_out) S2P_FAIL(-1, "s2p_l1_loss: null pointer");
   // every workgroup ends in ONE atomicAdd on the same loss word, and same-address atomics retire at ~13 ns each on
   // MI355X (2048 workgroups = a 29 us floor): 512 workgroups of 16-byte loads still saturate HBM
-  static const int l1_cap = getenv("S2P_L1_BLOCKS") ? atoi(getenv("S2P_L1_BLOCKS")) : 512;
+  static const int l1_cap = s2p_env_int("S2P_L1_BLOCKS", 512);
   dim3 g(grid_for(count / 4, l1_cap));
   if (dtype == S2P_F32) hipLaunchKernelGGL(l1_loss_kernel<float>, g, dim3(256), 0, (hipStream_t)stream, (const float*)a, (const float*)b, (long long)count, scale, loss_out, (float*)grad_a, accumulate);
   else if (dtype == S2P_BF16) hipLaunchKernelGGL(l1_loss_kernel<__bf16>, g, dim3(256), 0, (hipStream_t)stream, (const __bf16*)a, (const __bf16*)b, (long long)count, scale, loss_out, (__bf16*)grad_a, accumulate);

@@ -11,7 +11,6 @@
 //   sums   : opaque fp32 buffer [N][C][S][4] of per-split backward sums, summed by the consumer in split order.
 //   y  = act( xhat * (1 + g_img + g_st) + (b_img + b_st) ),   xhat = (x - mean) * rstd
 #include "s2p_common.h"
-#include <stdlib.h>
 
 struct NormArgs {
   const void* x; const void* da; const void* gb; const float* gbst; const float* stats; float* sums;

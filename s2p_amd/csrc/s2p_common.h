@@ -16,6 +16,22 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 #define S2P_WAVE 64
 
+// ---- diagnostics are a separate build ----------------------------------------------------------------------
+// Timing ablations (skip loads / skip MFMAs / clock stamps: outputs INVALID) and A/B environment switches exist only
+// in libs2p_hip_diag.so (build.sh diag -> -DS2P_DIAG_BUILD), which tools/ select with S2P_LIB.  In the product
+// library S2P_DIAGV() is the constant 0 (every ablation branch is compiled out of the kernels) and s2p_env_int()
+// never reads the environment: a stray variable in a training job cannot change a kernel.
+#ifdef S2P_DIAG_BUILD
+#include <stdlib.h>
+#define S2P_DIAGV(a) ((a).diag)
+static inline int s2p_env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+static inline int s2p_env_set(const char* name) { return getenv(name) ? 1 : 0; }
+#else
+#define S2P_DIAGV(a) 0
+static inline int s2p_env_int(const char*, int dflt) { return dflt; }
+static inline int s2p_env_set(const char*) { return 0; }
+#endif
+
 // ---- error plumbing ---------------------------------------------------------
 void s2p_set_error(const char* fmt, ...);
 #define S2P_FAIL(code, ...) do { s2p_set_error(__VA_ARGS__); return (code); } while (0)

@@ -447,7 +447,7 @@ int s2p_thin_tiled_fwd(const s2p_conv_desc* d, const void* x, const void* w, con
   a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = bias; a.y = (__bf16*)y; a.act = act; a.slope = slope;
   const int HW_ = TW + d->KH - 1, HH = TH + d->KH - 1;
   const size_t lds = (size_t)HW_ * HH * (d->Cin * 2 + 16) + (size_t)d->Cout * d->KH * d->KW * d->Cin * 2 + TW * TH * 16;
-  static const int no_static = getenv("S2P_NO_THIN_STATIC") ? 1 : 0;
+  static const int no_static = s2p_env_set("S2P_NO_THIN_STATIC");
   if (d->KH == 7 && d->Cin == 64 && !no_static) hipLaunchKernelGGL((thin_tiled_fwd_kernel<7, 64>), dim3(a.ntiles), dim3(256), lds, st, a);
   else hipLaunchKernelGGL((thin_tiled_fwd_kernel<0, 0>), dim3(a.ntiles), dim3(256), lds, st, a);
   S2P_CHECK_LAUNCH("thin_tiled_fwd_kernel");
@@ -462,7 +462,7 @@ int s2p_thin_tiled_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, 
   const size_t lds = (size_t)HW_ * HH * (d->Cin * 2 + 16) + 4 * TW * TH * 2;
   const int pairs = d->KH * d->KW * (d->Cin / 16);
   int blocks = a.ntiles < 512 ? a.ntiles : 512;
-  static const int no_static = getenv("S2P_NO_THIN_STATIC") ? 1 : 0;
+  static const int no_static = s2p_env_set("S2P_NO_THIN_STATIC");
   if (d->KH == 7 && d->Cin == 64 && !no_static) hipLaunchKernelGGL((thin_tiled_wgrad_kernel<25, 7, 64>), dim3(blocks), dim3(512), lds, st, a);
   else if (pairs <= 8 * 13) hipLaunchKernelGGL(thin_tiled_wgrad_kernel<13>, dim3(blocks), dim3(512), lds, st, a);
   else if (pairs <= 8 * 25) hipLaunchKernelGGL(thin_tiled_wgrad_kernel<25>, dim3(blocks), dim3(512), lds, st, a);

@@ -8,7 +8,6 @@
 // so that the four k-rows of one transposed read fall on disjoint banks.  Split-K over the pixel axis with
 // fp32 atomics whose wave-instruction shape is two 128-B row segments (the full-rate shape on this chip).
 #include "s2p_common.h"
-#include <stdlib.h>
 
 struct WgradArgs {
   const void* A; const void* B; float* dW; float* db;
@@ -312,10 +311,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
   int stage = 0;
   for (int kt = 0; kt < nsteps; ++kt) {
     int st2 = stage + (NST - 1); if (st2 >= NST) st2 -= NST;
-    if (kt + (NST - 1) < nsteps && a.diag != 1) issue(st2);
+    if (kt + (NST - 1) < nsteps && S2P_DIAGV(a) != 1) issue(st2);
     const char* At = smem + stage * 2 * TILE;
     const char* Bt = At + TILE;
-    if (a.diag != 2)
+    if (S2P_DIAGV(a) != 2)
 #pragma unroll
     for (int s = 0; s < BKP / 16; ++s) {
       s16x4 av[2][TT], bv[2][TT];
@@ -365,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
 
   const int r = lane & 31, h = lane >> 5;
   float* dWg = a.dW + (size_t)g * a.dw_gstride;
-  if (a.diag == 3) return;
+  if (S2P_DIAGV(a) == 3) return;
 #pragma unroll
   for (int j = 0; j < TT; ++j) {
     int n = b_tile * BT + wb0 + 32 * j + r;
@@ -443,13 +442,13 @@ extern "C" int s2p_conv2d_wgrad(const s2p_conv_desc* d, const void* x, const voi
   dim3 grid(a.na_tiles * a.nb_tiles, d->groups, a.splitk);
   hipStream_t st = (hipStream_t)stream;
   const long long abytes = (long long)d->N * a.Qh * a.Qw * a.a_pitch * 2, bbytes = (long long)d->N * a.Hi * a.Wi * a.b_pitch * 2;
-  static const int no_dma = getenv("S2P_NO_LDS_DMA") ? 1 : 0;
+  static const int no_dma = s2p_env_set("S2P_NO_LDS_DMA");
   const bool dense = a.a_pitch <= 1024 && a.b_pitch <= 1024;
   // Large-pitch (grouped / channel-sliced) operands: these launches are L2-latency-bound and live on occupancy, so they
   // take the 2-stage DMA kernel without the fused bias accumulators (126 VGPRs, 32 KiB LDS: 4 workgroups per CU; the
   // 3-stage + fused-bias form is 146 VGPRs / 48 KiB = 3 per CU and measured 930 us on the 12-group gamma/beta wgrad,
   // the register-staged kernel 670 us, this form 521 us).  The bias gradient is a separate channel-sum pass here.
-  static const int wide_dma = getenv("S2P_NO_WGRAD_WIDE_DMA") ? 0 : 1;
+  static const int wide_dma = (s2p_env_set("S2P_NO_WGRAD_WIDE_DMA") ? 0 : 1);
   if (d->dtype == S2P_BF16 && !no_dma && !dense && wide_dma && abytes < (1ll << 31) && bbytes < (1ll << 31)) {
     a.a_bytes = (unsigned)abytes; a.b_bytes = (unsigned)bbytes;
     a.db = nullptr;
@@ -471,10 +470,10 @@ extern "C" int s2p_conv2d_wgrad(const s2p_conv_desc* d, const void* x, const voi
   }
   if (d->dtype == S2P_BF16 && !no_dma && dense && abytes < (1ll << 31) && bbytes < (1ll << 31)) {
     a.a_bytes = (unsigned)abytes; a.b_bytes = (unsigned)bbytes;
-    static const int diag = getenv("S2P_DIAG") ? atoi(getenv("S2P_DIAG")) : 0;
+    static const int diag = s2p_env_int("S2P_DIAG", 0);
     a.diag = diag;
     a.db = db;                                  // fused bias gradient (groups: db is [groups][Cout])
-    static const int target = getenv("S2P_WGRAD_BLOCKS") ? atoi(getenv("S2P_WGRAD_BLOCKS")) : 384;
+    static const int target = s2p_env_int("S2P_WGRAD_BLOCKS", 384);
     // split count: (groups * splits) a multiple of 8 (one unit per XCD per round), enough workgroups to fill the chip
     const int tiles = a.na_tiles * a.nb_tiles;
     const int total = cdiv(a.M, 32);

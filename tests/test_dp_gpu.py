@@ -1,0 +1,64 @@
+"""Data-parallel equivalence on the real model: 2 ranks x batch 2 must reproduce 1 rank x batch 4
+-- parameter broadcast, SUM all-reduce of the flat gradient buffers, the 1/world factor folded into the fused Adam.
+The ranks are fresh child processes sharing GPU 0 with gloo as the transport (the driver's multi-GPU run uses the same
+code over RCCL); nothing is re-exec'ed from this (GPU-initialised) pytest process."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _run(world, tmp):
+    port = str(_free_port())
+    outs = [os.path.join(tmp, "w%d_r%d.pt" % (world, r)) for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), str(r), str(world), port, outs[r]],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    for p in procs:
+        try:
+            log, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, log.decode()[-3000:]
+    return [torch.load(o) for o in outs]
+
+
+def test_two_ranks_half_batches_equal_one_rank_full_batch(hip_device, tmp_path):
+    single = _run(1, str(tmp_path))[0]
+    r0, r1 = _run(2, str(tmp_path))
+    assert r0["world"] == r1["world"] == 2 and single["world"] == 1
+    # broadcast: rank 1 was seeded differently, both must have started from rank 0's weights (= the single run's)
+    assert torch.equal(r0["w0"], single["w0"]) and torch.equal(r1["w0"], r0["w0"])
+    # ranks stay bitwise in lock-step: same reduced gradients, same updated weights
+    for k in ("gG", "gD", "wG", "wD"):
+        assert torch.equal(r0[k], r1[k]), k
+    # mean of the shard gradients == full-batch gradient (every op of G and D is per-sample, every loss a batch mean)
+    for k in ("gG", "gD"):
+        err = float((r0[k].double() - single[k].double()).norm() / single[k].double().norm())
+        print("DP vs single-process %s: rel-L2 %.3e" % (k, err))
+        assert err < 1e-4, (k, err)
+    # updated master weights: Adam's first step moves a weight by lr * g / (|g| + eps); compare where g is well away from 0
+    for wk, gk, lrk in (("wG", "gG", "lrG"), ("wD", "gD", "lrD")):
+        g = single[gk]
+        big = g.abs() > 0.05 * g.abs().max()
+        diff = (r0[wk] - single[wk]).abs()[big]
+        assert int(big.sum()) > 1000
+        bad = int((diff > 0.02 * single[lrk]).sum())
+        print("DP vs single-process %s: %d of %d well-conditioned weights differ by more than 2 %% of lr" % (wk, bad, int(big.sum())))
+        assert bad <= 1e-5 * int(big.sum())
+        assert float((r0[wk] - single["w0" if wk == "wG" else wk]).abs().max()) > 0 if wk == "wG" else True
+    # losses are batch means: the average of the two ranks' values is the full-batch value
+    for k, v in single["losses"].items():
+        avg = 0.5 * (r0["losses"][k] + r1["losses"][k])
+        assert abs(avg - v) <= 1e-4 * max(abs(v), 1e-2), (k, avg, v)

@@ -29,6 +29,15 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES.keys())
 
 
+def test_product_library_reads_no_environment():
+    """Diagnostics (timing ablations, A/B switches) live only in the -DS2P_DIAG_BUILD library: the product .so does not
+    even import getenv, so a stray S2P_* variable in a training job cannot change a kernel."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--undefined-only", _lib._SO], capture_output=True, text=True).stdout
+    assert "hipLaunchKernel" in out or "hipModuleLaunchKernel" in out or "__hipPushCallConfiguration" in out
+    assert "getenv" not in out
+
+
 def test_struct_layouts_match_header():
     import ctypes
     assert ctypes.sizeof(_lib.ConvDesc) == 19 * 4

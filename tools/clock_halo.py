@@ -6,6 +6,7 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert
 import torch
 from s2p_amd import ops
 assert os.environ.get("S2P_DIAG") == "8", "run with S2P_DIAG=8"
+assert "diag" in os.environ.get("S2P_LIB", ""), "needs the diagnostics build: bash s2p_amd/csrc/build.sh diag; S2P_LIB=s2p_amd/csrc/libs2p_hip_diag.so"
 dev = torch.device("cuda:0"); dt = torch.bfloat16
 for (N, cin, label) in [(64, 256, "ResBlk conv bs64 (442 tiles)"), (74, 256, "510 tiles (2 per CU)"), (37, 256, "256 tiles (1 per CU)"), (74, 1024, "510 tiles, K=9216")]:
     cout = 256

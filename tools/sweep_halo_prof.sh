@@ -2,7 +2,7 @@
 # kernel-only durations (rocprofv3) of the halo conv sweep for a few S2P_DIAG ablations
 cd /tmp && export TMPDIR=/tmp
 for d in 0 3 5 4; do
-  S2P_DIAG=$d rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/sw_$d -- python3 $GRAFT_REPO_ROOT/tools/sweep_halo.py > /dev/null 2>&1
+  S2P_LIB=$GRAFT_REPO_ROOT/s2p_amd/csrc/libs2p_hip_diag.so S2P_DIAG=$d rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/sw_$d -- python3 $GRAFT_REPO_ROOT/tools/sweep_halo.py > /dev/null 2>&1
   echo "DIAG=$d"; python3 - <<PY
 import csv, glob
 f = glob.glob("$GRAFT_REPO_ROOT/gpurun_out/sw_$d/*/*_kernel_trace.csv")[0]
