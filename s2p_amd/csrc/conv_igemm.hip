@@ -488,7 +488,7 @@ static int launch_cfg(GatherArgs& a, int groups, hipStream_t st) {
   a.nco_tiles = cdiv(a.Cst, BCO);
   int splits = 1;
   a.splitk = 1; a.ksteps = 0;
-  if (sizeof(T) == 4 && a.act == S2P_ACT_NONE && a.epi == S2P_EPI_STORE) {
+  if (sizeof(T) == 4 && a.T == 1 && a.act == S2P_ACT_NONE && a.epi == S2P_EPI_STORE) {   // 1x1 only: spatial convs stay atomics-free (bitwise reproducible)
     // latency-bound fp32 linear layers (tiny M, long K, a handful of tiles): split K, accumulate with fp32 atomics
     const int nk = cdiv(a.Ktot, Mma<T>::BK);
     const int tiles = a.npix_tiles * a.nco_tiles * groups;

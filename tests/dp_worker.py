@@ -19,7 +19,7 @@ def main():
         dist.init_process_group(backend="gloo")
     B = 4                                                   # global batch; each rank takes B / world samples
     per = B // world
-    opt = TrainOptions().parse(["--env_type", "cheetah", "--batchSize", str(per), "--precision", "fp32", "--gpu_ids", "0",
+    opt = TrainOptions().parse(["--env_type", "cheetah", "--batchSize", str(per), "--precision", "bf16", "--gpu_ids", "0",
                                 "--checkpoints_dir", os.path.dirname(out)], quiet=True)
     torch.manual_seed(7 + rank)                             # ranks start from DIFFERENT weights: the broadcast must fix that
     tr = Pix2PixTrainer(opt)
@@ -33,11 +33,18 @@ def main():
     w0 = model.netG.store.master.detach().cpu().clone()
     tr.run_generator_one_step(data)
     gG = (model.netG.store.grad * tr.optimizer_G.grad_scale).detach().cpu().clone()
+    wG = model.netG.store.master.detach().cpu().clone()
+    # The D step makes its fake with the generator's weights.  Adam's first step is sign-like (lr * g / (|g| + eps)), so the
+    # just-updated G weights of the two runs differ by up to lr wherever a gradient is ~0 (e.g. the conv biases in front of
+    # an InstanceNorm), which moves bf16 roundings of the fake and flips LeakyReLU branches in D.  Put the initial G
+    # weights back so that the D-step comparison sees identical inputs in both runs.
+    model.netG.store.master.copy_(w0.to(model.netG.store.master.device))
+    model.netG.store.repack()
     tr.run_discriminator_one_step(data)
     gD = (model.netD.store.grad * tr.optimizer_D.grad_scale).detach().cpu().clone()
     torch.cuda.synchronize()
     losses = {k: float(v) for k, v in tr.get_latest_losses().items()}
-    torch.save(dict(w0=w0, gG=gG, gD=gD, wG=model.netG.store.master.detach().cpu(), wD=model.netD.store.master.detach().cpu(),
+    torch.save(dict(w0=w0, gG=gG, gD=gD, wG=wG, wD=model.netD.store.master.detach().cpu(),
                     losses=losses, world=tr.dp.world_size, lrG=tr.optimizer_G.param_groups[0]["lr"],
                     lrD=tr.optimizer_D.param_groups[0]["lr"]), out)
     if world > 1:

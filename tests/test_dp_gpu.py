@@ -43,11 +43,14 @@ def test_two_ranks_half_batches_equal_one_rank_full_batch(hip_device, tmp_path):
     # ranks stay bitwise in lock-step: same reduced gradients, same updated weights
     for k in ("gG", "gD", "wG", "wD"):
         assert torch.equal(r0[k], r1[k]), k
-    # mean of the shard gradients == full-batch gradient (every op of G and D is per-sample, every loss a batch mean)
+    # mean of the shard gradients == full-batch gradient (every op of G and D is per-sample, every loss a batch mean).  The
+    # production bf16 path has no atomics in any forward / dgrad kernel, so each sample's activations -- and with them
+    # every ReLU / LeakyReLU branch -- are bitwise the same in both runs; what differs is the summation order over the
+    # batch inside the weight-gradient kernels (fp32 accumulators) and the all-reduce.
     for k in ("gG", "gD"):
         err = float((r0[k].double() - single[k].double()).norm() / single[k].double().norm())
         print("DP vs single-process %s: rel-L2 %.3e" % (k, err))
-        assert err < 1e-4, (k, err)
+        assert err < 1e-5, (k, err)          # measured 2.5e-7 (G), 1.4e-7 (D)
     # updated master weights: Adam's first step moves a weight by lr * g / (|g| + eps); compare where g is well away from 0
     for wk, gk, lrk in (("wG", "gG", "lrG"), ("wD", "gD", "lrD")):
         g = single[gk]
