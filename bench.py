@@ -55,7 +55,8 @@ def spade_resblk_aggregate(recs, N, HW):
     the generator forward twice (G step, D step), so forward-kind launches are halved."""
     h = HW // 4
     def ms(r): return r["events"][0].elapsed_time(r["events"][1])
-    conv_shapes = {(N, h, h, 256, 256, 3, 1, 1, 0), (N, h, h, 128, 512, 3, 1, 12, 0), (N, h, h, 3, 1536, 3, 1, 1, 0)}
+    conv_shapes = {(N, h, h, 256, 256, 3, 1, 1, 0), (N, h, h, 256, 256, 3, 1, 12, 0), (N, h, h, 128, 512, 3, 1, 12, 0),
+                   (N, h, h, 3, 1536, 3, 1, 1, 0)}      # groups == 12: the batched weight-gradient launches
     flops = t_mfma = t_norm = nbytes = 0.0
     launches = 0
     for r in recs:

@@ -25,6 +25,10 @@ class ConvDesc(ctypes.Structure):
         "KH", "KW", "stride", "pad", "transposed", "reflect", "groups", "x_gstride", "y_gstride")]
 
 
+class WgradJob(ctypes.Structure):
+    _fields_ = [("x", c_void_p), ("dy", c_void_p), ("dw", c_void_p), ("db", c_void_p)]
+
+
 class PackJob(ctypes.Structure):
     _fields_ = [("src", c_void_p), ("dst_fwd", c_void_p), ("dst_bwd", c_void_p),
                 ("R", ctypes.c_int32), ("T", ctypes.c_int32), ("C", ctypes.c_int32),
@@ -41,6 +45,8 @@ SIGNATURES = {
     "s2p_conv2d_fwd": [_DESC, _P, _P, _P, _P, _P, c_int, c_float, c_int, _P],
     "s2p_conv2d_dgrad": [_DESC, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P],
     "s2p_conv2d_wgrad": [_DESC, _P, _P, _P, _P, c_int, c_int, c_int64, c_int, _P],
+    "s2p_conv2d_wgrad_batched_workspace": [_DESC, c_int, c_int, c_int],
+    "s2p_conv2d_wgrad_batched": [_DESC, ctypes.POINTER(WgradJob), c_int, c_int, c_int, _P, ctypes.c_size_t, _P],
     "s2p_reflect_pad_bwd": [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P],
     "s2p_channel_sum": [c_int, _P, c_int64, c_int, c_int, _P, _P],
     "s2p_in_stats": [c_int, _P, c_int, c_int, c_int, c_int, c_float, _P, _P],
@@ -76,7 +82,7 @@ SIGNATURES = {
     "s2p_copy_channels": [c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int64, c_int, _P],
     "s2p_image_metrics": [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P],
 }
-_RESTYPE = {"s2p_last_error": ctypes.c_char_p, "s2p_in_stats_floats": c_int64, "s2p_in_bwd_sums_floats": c_int64}
+_RESTYPE = {"s2p_last_error": ctypes.c_char_p, "s2p_conv2d_wgrad_batched_workspace": ctypes.c_size_t, "s2p_in_stats_floats": c_int64, "s2p_in_bwd_sums_floats": c_int64}
 
 _lib = None
 
@@ -103,7 +109,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the export is missing
             fn.argtypes = args
             fn.restype = _RESTYPE.get(name, c_int)
-        if L.s2p_version() < 101:
+        if L.s2p_version() < 102:
             raise RuntimeError("libs2p_hip.so is older than this package")
         _lib = L
     return _lib

@@ -267,16 +267,21 @@ class S2PGenerator(BaseNetwork):
         dgb_all = torch.empty_like(gb_all)
         dst_all = torch.empty_like(st_all)                              # [N, 12*2C]: filled by the 12 MAT backward passes
         N = st_all.shape[0]
+        # The 12 block convs' weight gradients do not feed the backward chain: they are deferred and run as ONE batched
+        # launch behind it (12 x 16 output tiles x K-splits fill the chip without split-K 16 atomics); their dY tensors
+        # (12 x 14 MB at bs 64) simply stay alive until then.
+        wjobs = []
         for b in reversed(range(self.n_blocks)):
             x, sA, nA, c0, sB, nB = ctx["blocks"][b]
             o0, o1 = (2 * b) * 2 * C, (2 * b + 1) * 2 * C
-            L[f"b{b}c1"].wgrad(nB, dx)
+            wjobs.append((L[f"b{b}c1"], nB, dx))
             d_nB = L[f"b{b}c1"].dgrad(dx, nB.shape)
             d_c0 = ops.in_bwd(d_nB, c0, C, sB, gb_all, o1, st_all, o1, ACT_LRELU, LRELU, dgb_all, o1, dst_all, o1)
-            L[f"b{b}c0"].wgrad(nA, d_c0)
+            wjobs.append((L[f"b{b}c0"], nA, d_c0))
             d_nA = L[f"b{b}c0"].dgrad(d_c0, nA.shape)
             d_xb = ops.in_bwd(d_nA, x, C, sA, gb_all, o0, st_all, o0, ACT_LRELU, LRELU, dgb_all, o0, dst_all, o0)
             dx = ops.add(dx, d_xb, out=d_xb)
+        ConvLayer.wgrad_many(wjobs)
         # image-conditioning branch (batched)
         actv, seg = ctx["actv"], ctx["seg"]
         L["gb"].wgrad(actv, dgb_all)

@@ -29,8 +29,36 @@ class ConvLayer:
 
     def wgrad(self, x, dy):
         """Accumulate weight (and bias) gradients straight into the flat grad buffer."""
+        g = self.geom
+        if g.groups > 1 and x.dtype == torch.bfloat16 and g.k == 3 and g.stride == 1 and g.pad == 1 and not g.transposed \
+                and g.groups <= 16 and g.cin % 64 == 0 and g.cout % 64 == 0:
+            # grouped 3x3 conv (the 12 gamma/beta heads): one job per group of the batched slab kernel
+            one = ConvGeom(g.cin, g.cout, 3, 1, 1)
+            gw = self.pk.gw.view(g.groups, -1)
+            gb = self.pk.gb.view(g.groups, -1) if self.pk.gb is not None else None
+            jobs = [(x, i * g.x_gstride, dy, i * g.y_gstride, gw[i], gb[i] if gb is not None else None)
+                    for i in range(g.groups)]
+            ops.conv_wgrad_batched(one, jobs, g.cin, self.cin_real, self.cout_real)
+            return
         ops.conv_wgrad(self.geom, x, dy, self.pk.gw, self.cin_pad(x.dtype), self.cin_real, self.cout_real,
                        dw_gstride=self.pk.gw_gstride, db=self.pk.gb)      # bias gradient fused into the wgrad pass
+
+    @staticmethod
+    def wgrad_many(items):
+        """items: list of (layer, x, dy) of layers with the SAME geometry: one batched launch when the slab kernel applies
+        (s2p_conv2d_wgrad_batched falls back to one launch per job otherwise)."""
+        if not items:
+            return
+        l0, x0, _ = items[0]
+        g = l0.geom
+        same = all(l.geom.__dict__ == g.__dict__ and x.shape == x0.shape and l.cin_real == l0.cin_real
+                   and l.cout_real == l0.cout_real for l, x, _ in items)
+        if not same or g.groups != 1 or len(items) > 16:
+            for l, x, dy in items:
+                l.wgrad(x, dy)
+            return
+        jobs = [(x, 0, dy, 0, l.pk.gw, l.pk.gb) for l, x, dy in items]
+        ops.conv_wgrad_batched(g, jobs, l0.cin_pad(x0.dtype), l0.cin_real, l0.cout_real)
 
 
 def make_conv_param(cout, cin, k):

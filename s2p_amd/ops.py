@@ -145,6 +145,30 @@ def conv_wgrad(geom, x, dy, dw, cin_pad, cin_real, cout_real, dw_gstride=0, spli
     pr.done()
 
 
+def conv_wgrad_batched(geom, jobs, cin_pad, cin_real, cout_real):
+    """dw_j += wgrad(x_j, dy_j), db_j += sum dy_j for several convs of the SAME geometry in one launch
+    (s2p_conv2d_wgrad_batched).  jobs: list of (x, x_ch_off, dy, dy_ch_off, dw, db): x / dy NHWC tensors (all the
+    same shape) read from channel offset *_ch_off (a grouped conv is one job per group), dw fp32 view, db fp32 view or
+    None.  `geom` must describe ONE group (groups == 1)."""
+    x0, _, dy0 = jobs[0][0], jobs[0][1], jobs[0][2]
+    N, H, W, xp = x0.shape
+    d = geom.desc(x0.dtype, N, H, W, cin_pad, xp, dy0.shape[3])
+    arr = (_lib.WgradJob * len(jobs))()
+    esz = x0.element_size()
+    for i, (x, xo, dy, dyo, dw, db) in enumerate(jobs):
+        assert x.shape == x0.shape and dy.shape == dy0.shape
+        arr[i] = _lib.WgradJob(ptr(x) + xo * esz, ptr(dy) + dyo * esz, ptr(dw), ptr(db))
+    need = lib().s2p_conv2d_wgrad_batched_workspace(ctypes.byref(d), len(jobs), cin_real, cout_real)
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x0.device)
+    pr = _Prof("wgrad", geom, N, H, W, x0.dtype)
+    if pr.on:
+        pr.rec["flops"] *= len(jobs)
+        pr.rec["shape"] = pr.rec["shape"][:7] + (len(jobs),) + pr.rec["shape"][8:]
+    check(lib().s2p_conv2d_wgrad_batched(ctypes.byref(d), arr, len(jobs), cin_real, cout_real, ptr(ws), need, stream()),
+          "s2p_conv2d_wgrad_batched")
+    pr.done()
+
+
 def channel_sum(dy, C, db):
     """db += dy.sum over pixels (bias gradient)."""
     pixels = dy.shape[0] * dy.shape[1] * dy.shape[2]

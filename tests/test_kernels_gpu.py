@@ -337,3 +337,55 @@ def test_posenc_losses_adam(hip_device):
         opt.step()
         ops.adam_step(pd, (gr * step).to(dev), m, v, 1e-3, 0.0, 0.9, 1e-8, step)
     assert rel_err(pd.cpu(), pt.detach()) < 1e-5
+
+
+@pytest.mark.parametrize("case", [
+    # n_jobs, cin, cout, H, W, N, grouped
+    (3, 64, 128, 9, 7, 3, False),       # ragged grid, several K blocks, pad rows / columns crossing block boundaries
+    (2, 128, 64, 21, 21, 2, False),     # the ResBlk grid
+    (4, 64, 64, 5, 5, 1, True),         # one job per group of a grouped conv (channel-offset pointers, wide pitches)
+    (1, 64, 64, 30, 36, 2, False),      # wider image: 192-row X window variant
+])
+def test_conv_wgrad_batched_slab(hip_device, case):
+    """s2p_conv2d_wgrad_batched (csrc/wgrad_slab.hip): padded-raster slab kernel + fixed-order partial reduction against
+    float64 autograd, accumulation into a non-zero dw / db, and bitwise reproducibility (no atomics)."""
+    nj, cin, cout, H, W, N, grouped = case
+    dev = hip_device
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(7 + nj)
+    geom = ops.ConvGeom(cin, cout, 3, 1, 1)
+    xs = torch.randn(N, nj * cin, H, W, generator=g).bfloat16().float()
+    dys = torch.randn(N, nj * cout, H, W, generator=g).bfloat16().float()
+    if grouped:
+        xd = nhwc(xs, nj * cin, dtype, dev); dyd = nhwc(dys, nj * cout, dtype, dev)
+    dw0 = torch.randn(nj, cout, 9, cin, generator=g)
+    db0 = torch.randn(nj, cout, generator=g)
+
+    def run():
+        dw = dw0.clone().to(dev); db = db0.clone().to(dev)
+        jobs = []
+        keep = []
+        for j in range(nj):
+            if grouped:
+                jobs.append((xd, j * cin, dyd, j * cout, dw[j], db[j]))
+            else:
+                xj = nhwc(xs[:, j * cin:(j + 1) * cin], cin, dtype, dev); dyj = nhwc(dys[:, j * cout:(j + 1) * cout], cout, dtype, dev)
+                keep += [xj, dyj]
+                jobs.append((xj, 0, dyj, 0, dw[j], db[j] if j != 1 else None))     # one job without a bias gradient
+        ops.conv_wgrad_batched(geom, jobs, cin, cin, cout)
+        torch.cuda.synchronize()
+        return dw.cpu(), db.cpu()
+
+    dw, db = run()
+    for j in range(nj):
+        xr = xs[:, j * cin:(j + 1) * cin].double()
+        wr = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+        F.conv2d(xr, wr, padding=1).backward(dys[:, j * cout:(j + 1) * cout].double())
+        ref = dw0[j].double() + wr.grad.permute(0, 2, 3, 1).reshape(cout, 9, cin)
+        assert rel_err(dw[j], ref) < 1e-5, j                       # bf16 operands are exact in fp32: only fp32 accumulation error
+        if grouped or j != 1:
+            assert rel_err(db[j], db0[j].double() + dys[:, j * cout:(j + 1) * cout].double().sum((0, 2, 3))) < 1e-5, j
+        else:
+            assert torch.equal(db[j], db0[j])
+    dw2, db2 = run()
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
