@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define S2P_VERSION 102
+#define S2P_VERSION 103
 
 enum { S2P_F32 = 0, S2P_BF16 = 1 };
 enum { S2P_ACT_NONE = 0, S2P_ACT_RELU = 1, S2P_ACT_LRELU = 2, S2P_ACT_TANH = 3, S2P_ACT_SWISH = 4 };
@@ -117,6 +117,12 @@ int s2p_in_apply_fwd(int dtype, const void* x, int N, int HW, int C, int pitch,
                      const float* stats, const void* gb_img, int gb_pitch,
                      const float* gb_st, int gb_st_pitch, int act, float slope, float eps,
                      void* y, int y_pitch, void* stream);
+/* s2p_in_stats + s2p_in_apply_fwd in one call: for planes of at most 512 (bf16) / 256 (fp32) pixels ONE fused launch
+ * reads x once, computes exact two-pass statistics and applies the modulation; larger planes run the two kernels.
+ * `stats` (s2p_in_stats_floats(N,HW,C) floats) is written in the same format either way, for the backward.        */
+int s2p_in_norm_fwd(int dtype, const void* x, int N, int HW, int C, int pitch, const void* gb_img, int gb_pitch,
+                    const float* gb_st, int gb_st_pitch, int act, float slope, float eps, void* y, int y_pitch,
+                    float* stats, void* stream);
 /* backward, given da = dL/dy (post-activation).  `sums` is an OPAQUE fp32 buffer of
  * s2p_in_bwd_sums_floats(N,HW,C) elements (per-split partial backward sums; written by
  * s2p_in_bwd_reduce, read by s2p_in_bwd_apply; no zero-init needed).

@@ -52,6 +52,8 @@ SIGNATURES = {
     "s2p_in_stats": [c_int, _P, c_int, c_int, c_int, c_int, c_float, _P, _P],
     "s2p_in_apply_fwd": [c_int, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, c_int, c_float,
                          c_float, _P, c_int, _P],
+    "s2p_in_norm_fwd": [c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, c_float, c_float, _P, c_int,
+                        _P, _P],
     "s2p_in_bwd_reduce": [c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, c_int,
                           c_float, c_float, _P, _P],
     "s2p_in_bwd_apply": [c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, c_int,
@@ -109,7 +111,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the export is missing
             fn.argtypes = args
             fn.restype = _RESTYPE.get(name, c_int)
-        if L.s2p_version() < 102:
+        if L.s2p_version() < 103:
             raise RuntimeError("libs2p_hip.so is older than this package")
         _lib = L
     return _lib

@@ -270,6 +270,117 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const NormArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused forward for small planes (HW * 16 B * MAXP fits a thread's registers: the 21x21 MAT norms of the ResBlks and
+// the small PatchGAN maps): ONE workgroup of 1024 threads owns a whole (image, 64-channel slab) plane, loads every
+// chunk of x (and gamma / beta) it needs up front (196 KB in flight per CU), computes the exact two-pass statistics
+// (mean, then centred second moment) with wave shuffles + LDS, and applies the modulation from registers: x is read
+// once instead of twice and the statistics pass is not a separate launch.  It also writes the statistics buffer in
+// the usual self-describing format (one split), so the backward kernels consume it unchanged.
+template <typename T>
+__global__ __launch_bounds__(1024) void in_fused_fwd_kernel(const NormArgs a) {
+  constexpr int CE = DT<T>::CE;
+  constexpr int CS = 64, NCH = CS / CE, PR = 1024 / NCH, MAXP = 4;     // bf16: 128 pixel rows x 4 = 512 pixels; fp32: 64 x 4
+  constexpr int RPW = 64 / NCH;                                        // pixel rows held by one wave: 8 / 4
+  __shared__ float red[16][CS];
+  __shared__ float cst[4][CS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cc = tid % NCH, pr = tid / NCH;
+  const int n = blockIdx.y, c0 = blockIdx.x * CS + cc * CE;
+  const bool cok = c0 < a.C;
+  const size_t img = (size_t)n * a.HW;
+  const T* xb = (const T*)a.x + img * a.x_pitch + c0;
+  const T* gbb = a.gb ? (const T*)a.gb + img * a.gb_pitch + c0 : nullptr;
+  Chunk<T> xv[MAXP], gv[MAXP], bv[MAXP];
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) {
+    const int p = pr + k * PR;
+    xv[k].raw = (u32x4){0u, 0u, 0u, 0u}; gv[k].raw = xv[k].raw; bv[k].raw = xv[k].raw;
+    if (cok && p < a.HW) {
+      xv[k].raw = *(const u32x4*)(xb + (size_t)p * a.x_pitch);
+      if (gbb) { gv[k].raw = *(const u32x4*)(gbb + (size_t)p * a.gb_pitch); bv[k].raw = *(const u32x4*)(gbb + (size_t)p * a.gb_pitch + a.C); }
+    }
+  }
+  // sum over the pixel rows of a wave (lanes that share cc differ in the lane bits above log2(NCH)), then over waves
+  auto plane_sum = [&](float (&v)[CE], int slot) {
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+#pragma unroll
+      for (int o = NCH; o < 64; o <<= 1) v[e] += __shfl_xor(v[e], o, 64);
+    }
+    __syncthreads();                                                   // red[] free again
+    if (lane < NCH) {
+#pragma unroll
+      for (int e = 0; e < CE; ++e) red[wave][lane * CE + e] = v[e];
+    }
+    __syncthreads();
+    if (tid < CS) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) t += red[w][tid];
+      cst[slot][tid] = t;
+    }
+    __syncthreads();
+  };
+  (void)RPW;
+  const float inv = 1.f / (float)a.HW;
+  float acc[CE], mean[CE], rstd[CE];
+#pragma unroll
+  for (int e = 0; e < CE; ++e) {
+    acc[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) acc[e] += xv[k].get(e);            // missing pixels were loaded as zeros
+  }
+  plane_sum(acc, 0);
+#pragma unroll
+  for (int e = 0; e < CE; ++e) {
+    mean[e] = cst[0][cc * CE + e] * inv;
+    acc[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+      const float d = xv[k].get(e) - mean[e];
+      acc[e] += (pr + k * PR < a.HW) ? d * d : 0.f;
+    }
+  }
+  plane_sum(acc, 1);
+  if (tid < CS) {
+    const int c = blockIdx.x * CS + tid;
+    if (c < a.C) {
+      float* o = (float*)a.stats + STATS_HDR + ((size_t)n * a.C + c) * 2;
+      o[0] = cst[0][tid] * inv; o[1] = cst[1][tid];
+      if (c == 0 && n == 0) *(i32x4*)a.stats = (i32x4){1, a.HW, 0, 0};
+      cst[2][tid] = a.gbst ? 1.f + a.gbst[(size_t)n * a.gbst_pitch + c] : 1.f;
+      cst[3][tid] = a.gbst ? a.gbst[(size_t)n * a.gbst_pitch + a.C + c] : 0.f;
+    }
+  }
+  __syncthreads();
+  if (!cok) return;
+  float gs[CE], bs[CE];
+#pragma unroll
+  for (int e = 0; e < CE; ++e) {
+    rstd[e] = 1.f / sqrtf(cst[1][cc * CE + e] * inv + a.eps);
+    gs[e] = cst[2][cc * CE + e]; bs[e] = cst[3][cc * CE + e];
+  }
+  const float ns = a.act == S2P_ACT_RELU ? 0.f : (a.act == S2P_ACT_LRELU ? a.slope : 1.f);
+  const bool act_generic = a.act == S2P_ACT_TANH || a.act == S2P_ACT_SWISH;
+  T* yb = (T*)a.y + img * a.y_pitch + c0;
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) {
+    const int p = pr + k * PR;
+    if (p >= a.HW) break;
+    Chunk<T> o0;
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+      float gg = gs[e] + (gbb ? gv[k].get(e) : 0.f);
+      float bb = bs[e] + (gbb ? bv[k].get(e) : 0.f);
+      float xh;
+      float yv = mat_value(xv[k].get(e), mean[e], rstd[e], gg, bb, xh);
+      o0.set(e, act_generic ? act_fwd(yv, a.act, a.slope) : (yv > 0.f ? yv : yv * ns));
+    }
+    *(u32x4*)(yb + (size_t)p * a.y_pitch) = o0.raw;
+  }
+}
+
 // per-channel sum over pixels (bias gradient)
 template <typename T>
 __global__ __launch_bounds__(256) void channel_sum_kernel(const T* dy, long long pixels, int C, int pitch,
@@ -365,6 +476,27 @@ extern "C" int s2p_in_apply_fwd(int dtype, const void* x, int N, int HW, int C, 
   a.N = N; a.HW = HW; a.C = C; a.x_pitch = pitch; a.gb_pitch = gb_pitch; a.gbst_pitch = gb_st_pitch;
   a.y_pitch = y_pitch; a.act = act; a.slope = slope; a.eps = eps;
   return launch_apply<0>(dtype, a, (hipStream_t)stream);
+}
+
+// statistics + apply in one call: one fused launch for small planes, otherwise the two-kernel path
+extern "C" int s2p_in_norm_fwd(int dtype, const void* x, int N, int HW, int C, int pitch, const void* gb_img, int gb_pitch,
+                               const float* gb_st, int gb_st_pitch, int act, float slope, float eps, void* y, int y_pitch,
+                               float* stats, void* stream) {
+  int rc = norm_check("s2p_in_norm_fwd", dtype, C, pitch, gb_pitch, y_pitch); if (rc) return rc;
+  if (!x || !y || !stats || N <= 0 || HW <= 0) S2P_FAIL(-1, "s2p_in_norm_fwd: null pointer / empty problem");
+  const int maxhw = dtype == S2P_F32 ? 256 : 512;
+  if (HW > maxhw || s2p_env_set("S2P_NO_FUSED_NORM")) {
+    rc = s2p_in_stats(dtype, x, N, HW, C, pitch, eps, stats, stream); if (rc) return rc;
+    return s2p_in_apply_fwd(dtype, x, N, HW, C, pitch, stats, gb_img, gb_pitch, gb_st, gb_st_pitch, act, slope, eps, y, y_pitch, stream);
+  }
+  NormArgs a{}; a.x = x; a.stats = stats; a.gb = gb_img; a.gbst = gb_st; a.y = y;
+  a.N = N; a.HW = HW; a.C = C; a.x_pitch = pitch; a.gb_pitch = gb_pitch; a.gbst_pitch = gb_st_pitch;
+  a.y_pitch = y_pitch; a.act = act; a.slope = slope; a.eps = eps;
+  dim3 grid(cdiv(C, 64), N);
+  if (dtype == S2P_F32) hipLaunchKernelGGL(in_fused_fwd_kernel<float>, grid, dim3(1024), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(in_fused_fwd_kernel<__bf16>, grid, dim3(1024), 0, (hipStream_t)stream, a);
+  S2P_CHECK_LAUNCH("in_fused_fwd_kernel");
+  return 0;
 }
 
 extern "C" int s2p_in_bwd_reduce(int dtype, const void* da, int da_pitch, const void* x, int N, int HW, int C,

@@ -293,6 +293,7 @@ static int ws_splits(const s2p_conv_desc* d, int n_jobs) {
 }
 
 extern "C" size_t s2p_conv2d_wgrad_batched_workspace(const s2p_conv_desc* d, int n_jobs, int cin_real, int cout_real) {
+  if (d && n_jobs >= 1 && s2p_head_wgrad_supported(d, cin_real, cout_real)) return (size_t)n_jobs * s2p_head_wgrad_workspace(d);
   if (!d || !ws_supported(d, n_jobs, cin_real, cout_real)) return 0;
   const int S = ws_splits(d, n_jobs);
   if (S == 1) return 0;
@@ -305,6 +306,17 @@ extern "C" int s2p_conv2d_wgrad_batched(const s2p_conv_desc* d, const s2p_wgrad_
   if (!d || !jobs || n_jobs < 1) S2P_FAIL(-1, "s2p_conv2d_wgrad_batched: null pointer / no jobs");
   for (int j = 0; j < n_jobs; ++j)
     if (!jobs[j].x || !jobs[j].dy || !jobs[j].dw) S2P_FAIL(-1, "s2p_conv2d_wgrad_batched: job %d has a null pointer", j);
+  if (s2p_head_wgrad_supported(d, cin_real, cout_real)) {
+    // PatchGAN logit heads (Cout = 1): activation-stationary kernel + fixed-order partial reduce (csrc/wgrad_head.hip)
+    const size_t per = s2p_head_wgrad_workspace(d);
+    if (!workspace || workspace_bytes < per * n_jobs) S2P_FAIL(-1, "s2p_conv2d_wgrad_batched: workspace of %zu bytes needed", per * n_jobs);
+    for (int j = 0; j < n_jobs; ++j) {
+      int rc = s2p_head_wgrad(d, jobs[j].x, jobs[j].dy, jobs[j].dw, jobs[j].db, cin_real, (char*)workspace + j * per, per,
+                              (hipStream_t)stream);
+      if (rc) return rc;
+    }
+    return 0;
+  }
   if (!ws_supported(d, n_jobs, cin_real, cout_real)) {
     // geometry outside the slab kernel's scope (other taps / strides / dtypes): one generic launch per job
     for (int j = 0; j < n_jobs; ++j) {

@@ -64,8 +64,7 @@ class NLayerDiscriminator(BaseNetwork):
             xin = f
             c = self.lay[n].fwd(xin)
             C = self.chans[n]
-            s = ops.in_stats(c, C)
-            f = ops.in_apply_fwd(c, C, s, act=ACT_LRELU, slope=LRELU)
+            f, s = ops.in_norm_fwd(c, C, act=ACT_LRELU, slope=LRELU)
             feats.append(f)
             saved.append((xin, c, s, f))
         out = self.lay[nl].fwd(f)

@@ -197,16 +197,14 @@ class S2PGenerator(BaseNetwork):
         # encoder
         enc = []
         x = L["stem"].fwd(img)
-        s = ops.in_stats(x, self.ngf)
-        a = ops.in_apply_fwd(x, self.ngf, s, act=ACT_RELU)
+        a, s = ops.in_norm_fwd(x, self.ngf, act=ACT_RELU)
         enc.append((img, x, s, a))
         c = self.ngf
         for i in range(self.n_down):
             xin = a
             x = L[f"down{i}"].fwd(xin)
             c *= 2
-            s = ops.in_stats(x, c)
-            a = ops.in_apply_fwd(x, c, s, act=ACT_RELU)
+            a, s = ops.in_norm_fwd(x, c, act=ACT_RELU)
             enc.append((xin, x, s, a))
         # MAT residual blocks
         main.wait_stream(side)                                          # st_all is needed from here on
@@ -214,11 +212,9 @@ class S2PGenerator(BaseNetwork):
         x = a
         for b in range(self.n_blocks):
             o0, o1 = (2 * b) * 2 * C, (2 * b + 1) * 2 * C
-            sA = ops.in_stats(x, C)
-            nA = ops.in_apply_fwd(x, C, sA, gb_all, o0, st_all, o0, ACT_LRELU, LRELU)
+            nA, sA = ops.in_norm_fwd(x, C, gb_all, o0, st_all, o0, ACT_LRELU, LRELU)
             c0 = L[f"b{b}c0"].fwd(nA)
-            sB = ops.in_stats(c0, C)
-            nB = ops.in_apply_fwd(c0, C, sB, gb_all, o1, st_all, o1, ACT_LRELU, LRELU)
+            nB, sB = ops.in_norm_fwd(c0, C, gb_all, o1, st_all, o1, ACT_LRELU, LRELU)
             xn = L[f"b{b}c1"].fwd(nB, aux=x, epi=EPI_ADD)
             blocks.append((x, sA, nA, c0, sB, nB))
             x = xn
@@ -228,8 +224,7 @@ class S2PGenerator(BaseNetwork):
             xin = x
             u = L[f"up{i}"].fwd(xin)
             c //= 2
-            s = ops.in_stats(u, c)
-            x = ops.in_apply_fwd(u, c, s, act=ACT_RELU)
+            x, s = ops.in_norm_fwd(u, c, act=ACT_RELU)
             dec.append((xin, u, s, x))
         out = L["out"].fwd(x, act=ACT_TANH)
         if save:

@@ -40,6 +40,11 @@ class ConvLayer:
                     for i in range(g.groups)]
             ops.conv_wgrad_batched(one, jobs, g.cin, self.cin_real, self.cout_real)
             return
+        if g.groups == 1 and g.cout == 1 and x.dtype == torch.bfloat16 and g.stride == 1 and not g.transposed and not g.reflect:
+            # PatchGAN logit head: activation-stationary kernel behind the batched entry point (it needs a workspace)
+            ops.conv_wgrad_batched(g, [(x, 0, dy, 0, self.pk.gw, self.pk.gb)], self.cin_pad(x.dtype), self.cin_real,
+                                   self.cout_real)
+            return
         ops.conv_wgrad(self.geom, x, dy, self.pk.gw, self.cin_pad(x.dtype), self.cin_real, self.cout_real,
                        dw_gstride=self.pk.gw_gstride, db=self.pk.gb)      # bias gradient fused into the wgrad pass
 

@@ -207,6 +207,20 @@ def in_apply_fwd(x, C, stats, gb=None, gb_off=0, gb_st=None, st_off=0, act=ACT_N
     return y
 
 
+def in_norm_fwd(x, C, gb=None, gb_off=0, gb_st=None, st_off=0, act=ACT_NONE, slope=0.2):
+    """in_stats + in_apply_fwd as ONE call (one fused launch for small planes): returns (y, stats)."""
+    N, H, W, xp = x.shape
+    stats = torch.empty(lib().s2p_in_stats_floats(N, H * W, C), dtype=torch.float32, device=x.device)
+    y = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
+    gbp, gb_pitch, stp, st_pitch = _gb_args(gb, gb_off, gb_st, st_off)
+    esz = x.element_size()
+    pr = _ProfNorm("norm_fwd", x, C, N * H * W * C * esz * ((4 if gb is not None else 2) + 1), gb is not None)
+    check(lib().s2p_in_norm_fwd(dtype_id(x.dtype), ptr(x), N, H * W, C, xp, gbp, gb_pitch, stp, st_pitch, act, slope, IN_EPS,
+                                ptr(y), C, ptr(stats), stream()), "s2p_in_norm_fwd")
+    pr.done()
+    return y, stats
+
+
 def in_bwd(da, x, C, stats, gb=None, gb_off=0, gb_st=None, st_off=0, act=ACT_NONE, slope=0.2, dgb=None, dgb_off=0,
            dgb_st=None, dst_off=0):
     """Backward of in_apply_fwd.  Returns dx; writes d(gamma_img|beta_img) into dgb at channel offset dgb_off and

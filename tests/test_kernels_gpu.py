@@ -217,6 +217,13 @@ def test_instance_norm_mat(hip_device, dtype, modulated):
         assert rel_err(nchw(dgb[..., C:], C), br.grad) < tol
         assert rel_err(dst[:, 4:4 + 2 * C].cpu(), sr.grad) < tol
         assert float(dst[:, :4].min()) == 7.0 and float(dst[:, 4 + 2 * C:].min()) == 7.0      # nothing else touched
+    # the one-call form (fused statistics + apply launch for small planes) and its statistics buffer fed to the backward
+    y3, stats3 = ops.in_norm_fwd(xd, C, gb, 0, std, 0, act, 0.2)
+    assert rel_err(nchw(y3, C), y_ref.detach()) < tol
+    dx3 = ops.in_bwd(nhwc(da, C, dtype, dev), xd, C, stats3, gb, 0, std, 0, act, 0.2, dgb, 0, dst, 4)
+    assert rel_err(nchw(dx3, C), xr.grad) < tol * 2
+    y4, stats4 = ops.in_norm_fwd(xd, C, gb, 0, std, 0, act, 0.2)
+    assert torch.equal(y3, y4) and torch.equal(stats3, stats4)
     # no atomics anywhere in the norm kernels: a second run is bitwise identical
     stats2 = ops.in_stats(xd, C)
     y2 = ops.in_apply_fwd(xd, C, stats2, gb, 0, std, 0, act, 0.2)
@@ -224,7 +231,7 @@ def test_instance_norm_mat(hip_device, dtype, modulated):
     assert torch.equal(stats, stats2) and torch.equal(y, y2) and torch.equal(dx, dx2)
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 21, 21), (1, 64, 84, 84), (3, 68, 9, 7)])
+@pytest.mark.parametrize("shape", [(2, 64, 21, 21), (1, 64, 84, 84), (3, 68, 9, 7), (2, 132, 16, 16)])
 def test_instance_norm_large_mean(hip_device, shape):
     """|mean| / std = 1e3 (a near-constant, strongly biased channel): single-pass raw moments E[x^2] - E[x]^2 lose all
     digits here; the pivot-shifted partial moments + Chan merge must not.  fp32, against float64, 1e-3 (the input's own
@@ -245,6 +252,9 @@ def test_instance_norm_large_mean(hip_device, shape):
     torch.cuda.synchronize()
     assert rel_err(nchw(y, C), y_ref.detach()) < 1e-3
     assert rel_err(nchw(dx, C), xr.grad) < 2e-3
+    y3, stats3 = ops.in_norm_fwd(xd, C, act=ACT_NONE)                       # fused launch when the plane has <= 256 pixels
+    dx3 = ops.in_bwd(nhwc(da, C, torch.float32, dev), xd, C, stats3, act=ACT_NONE)
+    assert rel_err(nchw(y3, C), y_ref.detach()) < 1e-3 and rel_err(nchw(dx3, C), xr.grad) < 2e-3
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -387,5 +397,35 @@ def test_conv_wgrad_batched_slab(hip_device, case):
             assert rel_err(db[j], db0[j].double() + dys[:, j * cout:(j + 1) * cout].double().sum((0, 2, 3))) < 1e-5, j
         else:
             assert torch.equal(db[j], db0[j])
+    dw2, db2 = run()
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+@pytest.mark.parametrize("case", [(512, 4, 13, 13, 5), (128, 4, 8, 7, 3), (64, 3, 9, 9, 2)])
+def test_conv_wgrad_head(hip_device, case):
+    """PatchGAN logit head (Cout = 1, stride 1, pad 2): activation-stationary wgrad (csrc/wgrad_head.hip) behind
+    s2p_conv2d_wgrad_batched, against float64 autograd; accumulates into dw / db; bitwise reproducible."""
+    cin, k, H, W, N = case
+    dev = hip_device
+    g = torch.Generator().manual_seed(cin + k)
+    pad = 2
+    x = torch.randn(N, cin, H, W, generator=g).bfloat16().float()
+    geom = ops.ConvGeom(cin, 1, k, 1, pad)
+    Ho, Wo = geom.out_hw(H, W)
+    dy = torch.randn(N, 1, Ho, Wo, generator=g).bfloat16().float()
+    dw0 = torch.randn(1, k * k, cin, generator=g); db0 = torch.randn(1, generator=g)
+    xd = nhwc(x, cin, torch.bfloat16, dev); dyd = nhwc(dy, 8, torch.bfloat16, dev)
+
+    def run():
+        dw = dw0.clone().to(dev); db = db0.clone().to(dev)
+        ops.conv_wgrad_batched(geom, [(xd, 0, dyd, 0, dw, db)], cin, cin, 1)
+        torch.cuda.synchronize()
+        return dw.cpu(), db.cpu()
+
+    dw, db = run()
+    wr = torch.zeros(1, cin, k, k, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wr, padding=pad).backward(dy.double())
+    assert rel_err(dw, dw0.double() + wr.grad.permute(0, 2, 3, 1).reshape(1, k * k, cin)) < 1e-5
+    assert rel_err(db, db0.double() + dy.double().sum()) < 1e-5
     dw2, db2 = run()
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
