@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define S2P_VERSION 103
+#define S2P_VERSION 104
 
 enum { S2P_F32 = 0, S2P_BF16 = 1 };
 enum { S2P_ACT_NONE = 0, S2P_ACT_RELU = 1, S2P_ACT_LRELU = 2, S2P_ACT_TANH = 3, S2P_ACT_SWISH = 4 };
@@ -143,6 +143,22 @@ int s2p_in_bwd_apply(int dtype, const void* da, int da_pitch, const void* x, int
 /* out[n][0:S]=s, then for k<L: sin(2^k s), cos(2^k s); columns >= S*(1+2L) up to out_pitch
  * are zero-filled.  fp32 in / fp32 out.                                                 */
 int s2p_posenc_fwd(const float* state, int N, int S, int L, float* out, int out_pitch, void* stream);
+
+/* Small fp32 linear layers of the state path (replaces F.linear + LeakyReLU and their autograd backward for the
+ * StateMapping MLP and the per-norm state affine; batch M of a few dozen rows: latency-bound, csrc/linear_small.hip).
+ * y[M][y_pitch] = act(x[M][K] . w[N][w_row]^T + bias[N]); columns [N, n_store) of y are written as zeros.
+ * K, pitches and w_row must be multiples of 4 floats.                                    */
+int s2p_linear_fwd(const float* x, int M, int K, int x_pitch, const float* w, int w_row, const float* bias, int N,
+                   int act, float slope, float* y, int y_pitch, int n_store, void* stream);
+/* Backward given dy = dL/dy and the layer OUTPUT y (needed when act != NONE; dpre = dy * act'(y)):
+ *   dw[N][dw_row] += dpre^T . x (columns < k_real), db[N] += sum_m dpre (db may be NULL),
+ *   dx[M][dx_pitch] = dpre . w  (dx may be NULL; needs w_bwd [K][wb_row], the transpose of w).
+ * No atomics: fixed summation order.  workspace: s2p_linear_bwd_workspace(M,K,N) bytes (0 for N < 2048). */
+size_t s2p_linear_bwd_workspace(int M, int K, int N);
+int s2p_linear_bwd(const float* x, int x_pitch, const float* dy, int dy_pitch, const float* y, int y_pitch, int M,
+                   int K, int k_real, int N, const float* w_bwd, int wb_row, int act, float slope, float* dw,
+                   int dw_row, float* db, float* dx, int dx_pitch, void* workspace, size_t workspace_bytes,
+                   void* stream);
 
 /* ---- pooling / resize / layout ---------------------------------------------------- */
 /* F.avg_pool2d(k=3,s=2,p=1,count_include_pad=False) and its backward                   */

@@ -60,6 +60,10 @@ SIGNATURES = {
                          c_float, c_float, _P, _P, c_int, _P, c_int, _P, c_int, _P],
     "s2p_in_stats_floats": [c_int, c_int, c_int],
     "s2p_in_bwd_sums_floats": [c_int, c_int, c_int],
+    "s2p_linear_fwd": [_P, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, c_float, _P, c_int, c_int, _P],
+    "s2p_linear_bwd_workspace": [c_int, c_int, c_int],
+    "s2p_linear_bwd": [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_float, _P, c_int, _P, _P,
+                       c_int, _P, ctypes.c_size_t, _P],
     "s2p_posenc_fwd": [_P, c_int, c_int, c_int, _P, c_int, _P],
     "s2p_avgpool3x3s2_fwd": [c_int, _P, c_int, c_int, c_int, c_int, _P, _P],
     "s2p_avgpool3x3s2_bwd": [c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P],
@@ -84,7 +88,7 @@ SIGNATURES = {
     "s2p_copy_channels": [c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int64, c_int, _P],
     "s2p_image_metrics": [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P],
 }
-_RESTYPE = {"s2p_last_error": ctypes.c_char_p, "s2p_conv2d_wgrad_batched_workspace": ctypes.c_size_t, "s2p_in_stats_floats": c_int64, "s2p_in_bwd_sums_floats": c_int64}
+_RESTYPE = {"s2p_last_error": ctypes.c_char_p, "s2p_conv2d_wgrad_batched_workspace": ctypes.c_size_t, "s2p_linear_bwd_workspace": ctypes.c_size_t, "s2p_in_stats_floats": c_int64, "s2p_in_bwd_sums_floats": c_int64}
 
 _lib = None
 
@@ -111,7 +115,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the export is missing
             fn.argtypes = args
             fn.restype = _RESTYPE.get(name, c_int)
-        if L.s2p_version() < 103:
+        if L.s2p_version() < 104:
             raise RuntimeError("libs2p_hip.so is older than this package")
         _lib = L
     return _lib

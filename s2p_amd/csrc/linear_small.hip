@@ -1,0 +1,245 @@
+// The state path: positional encoding -> 4 x (Linear + LeakyReLU) -> per-norm affine
+// Linear(256 -> 12*2C), all fp32, M = batch (64) rows.  0.6 MFLOP per image: these layers are LATENCY-bound, and the
+// generic implicit-GEMM conv kernel spends ~45 us per layer on them (2 workgroups, a 16..23-step staged K loop).
+// Here a layer is one short launch of many small workgroups:
+//   forward / dgrad : y[M][N] = f(x)[M][Kr] . W[N][Kr]^T (+ bias, activation)   tile = 64 rows x 16 columns per workgroup,
+//                     a thread owns 4 rows x 1 column; optional split of the reduction Kr over blockIdx.z with partial
+//                     tiles in a workspace and a fixed-order reduce (the 6144-deep dgrad of the affine layer);
+//   wgrad (+ bias)  : dW[N][K] += sum_m dpre[m][n] x[m][k]                       tile = 16 n x 64 k, loop over the batch;
+// where f / dpre fold the LeakyReLU derivative of the layer's saved OUTPUT into the operand staging, so the backward of a
+// layer is two short launches (wgrad + bias grad; dgrad) -- no act_bwd pass, no atomics, fixed summation order.
+// (One launch per layer, not one per chain: a layer needs every output of the previous one, and on this chip a kernel
+// boundary (~1.5 us, hipGraph) is cheaper than an in-kernel grid barrier (~4-7 us).)
+#include "s2p_common.h"
+
+struct LinArgs {
+  const float* x; const float* xact; const float* w; const float* bias; float* y; float* part;
+  // backward extras
+  const float* dy; const float* yact; const float* xin; float* dw; float* db;
+  int M, Kr, N, x_pitch, xact_pitch, w_row, y_pitch, n_store;
+  int act, in_act; float slope;
+  int ksplit, k_per_split;
+  // wgrad
+  int K, xin_pitch, dy_pitch, yact_pitch, dw_row, k_real;
+};
+
+__device__ __forceinline__ float lin_actgrad(float yv, int act, float slope) {
+  return act == S2P_ACT_LRELU ? (yv > 0.f ? 1.f : slope) : (act == S2P_ACT_RELU ? (yv > 0.f ? 1.f : 0.f) : 1.f);
+}
+
+// y tile [64 rows][16 cols] of  x'[M][Kr] . W[N][Kr]^T,  x' = x * act'(xact) when xact != nullptr
+__device__ __forceinline__ void lin_gemm_tile(const LinArgs& a, int mb, int nb, int k0, int k1, float (&acc)[4], float* xs, float* ws) {
+  constexpr int KC = 64, LD = KC + 1;
+  const int t = threadIdx.x, mq = t & 15, c = t >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = 0.f;
+  for (int kc = k0; kc < k1; kc += KC) {
+    __syncthreads();
+    // stage x' : 64 rows x 64 k  (4 float4 per thread), W : 16 rows x 64 k (1 float4 per thread)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = t + 256 * i, r = idx >> 4, q = idx & 15;
+      const int m = mb + r, k = kc + q * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < a.M && k < k1) {
+        v = *(const f32x4*)(a.x + (size_t)m * a.x_pitch + k);
+        if (a.xact) {
+          const f32x4 yv = *(const f32x4*)(a.xact + (size_t)m * a.xact_pitch + k);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= lin_actgrad(yv[e], a.in_act, a.slope);
+        }
+        if (k + 4 > k1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (k + e >= k1) v[e] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xs[r * LD + q * 4 + e] = v[e];
+    }
+    {
+      const int r = t >> 4, q = t & 15;
+      const int n = nb + r, k = kc + q * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (n < a.N && k < k1) {
+        v = *(const f32x4*)(a.w + (size_t)n * a.w_row + k);
+        if (k + 4 > k1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (k + e >= k1) v[e] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ws[r * LD + q * 4 + e] = v[e];
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < KC; ++k) {
+      const float wv = ws[c * LD + k];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_fmaf(xs[(4 * mq + i) * LD + k], wv, acc[i]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void lin_fwd_kernel(const LinArgs a) {
+  __shared__ float xs[64 * 65], ws[16 * 65];
+  const int nb = blockIdx.x * 16, mb = blockIdx.y * 64, z = blockIdx.z;
+  const int k0 = z * a.k_per_split, k1 = k0 + a.k_per_split < a.Kr ? k0 + a.k_per_split : a.Kr;
+  float acc[4];
+  lin_gemm_tile(a, mb, nb, k0, k1, acc, xs, ws);
+  const int t = threadIdx.x, mq = t & 15, c = t >> 4, n = nb + c;
+  if (n >= a.n_store) return;
+  if (a.ksplit > 1) {                                     // partial tile -> workspace [z][M][n_store]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mb + 4 * mq + i;
+      if (m < a.M) a.part[((size_t)z * a.M + m) * a.n_store + n] = acc[i];
+    }
+    return;
+  }
+  const float b = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = mb + 4 * mq + i;
+    if (m < a.M) {
+      float v = n < a.N ? acc[i] + b : 0.f;
+      v = a.act == S2P_ACT_LRELU ? (v > 0.f ? v : v * a.slope) : (a.act == S2P_ACT_RELU ? (v > 0.f ? v : 0.f) : v);
+      a.y[(size_t)m * a.y_pitch + n] = v;
+    }
+  }
+}
+
+// y[m][n] = sum over the K splits, in split order
+__global__ __launch_bounds__(256) void lin_splitk_reduce_kernel(const LinArgs a) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)a.M * a.n_store) return;
+  const int m = (int)(i / a.n_store), n = (int)(i - (long long)m * a.n_store);
+  float s = 0.f;
+  for (int z = 0; z < a.ksplit; ++z) s += a.part[((size_t)z * a.M + m) * a.n_store + n];
+  a.y[(size_t)m * a.y_pitch + n] = s;
+}
+
+// dW[N][K] += dpre^T x, db[N] += sum_m dpre   (dpre = dy * act'(y))
+__global__ __launch_bounds__(256) void lin_wgrad_kernel(const LinArgs a) {
+  __shared__ float xs[64 * 65], ws[64 * 17];
+  const int t = threadIdx.x;
+  // ---- wgrad tile: 16 outputs n x 64 inputs k; dpre staged [m][16], x staged [m][64]; thread = (4 k, 1 n) ----------
+  const int kt_n = (a.K + 63) / 64;
+  const int nb = (blockIdx.x / kt_n) * 16, kb = (blockIdx.x % kt_n) * 64;
+  const int kq = t & 15, c = t >> 4;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float accb = 0.f;
+  float* ds = ws;                                          // [64 m][16 n] (+1 pad)
+  for (int mb = 0; mb < a.M; mb += 64) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                          // x : 64 rows x 64 k
+      const int idx = t + 256 * i, r = idx >> 4, q = idx & 15;
+      const int m = mb + r, k = kb + q * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < a.M && k < a.K) v = *(const f32x4*)(a.xin + (size_t)m * a.xin_pitch + k);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xs[r * 65 + q * 4 + e] = v[e];
+    }
+    {                                                      // dpre : 64 rows x 16 n
+      const int r = t >> 2, q = t & 3;
+      const int m = mb + r, n = nb + q * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < a.M && n < a.N) {
+        v = *(const f32x4*)(a.dy + (size_t)m * a.dy_pitch + n);
+        if (a.yact) {
+          const f32x4 yv = *(const f32x4*)(a.yact + (size_t)m * a.yact_pitch + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= lin_actgrad(yv[e], a.act, a.slope);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ds[r * 17 + q * 4 + e] = v[e];
+    }
+    __syncthreads();
+    const int mlim = a.M - mb < 64 ? a.M - mb : 64;
+    for (int m = 0; m < mlim; ++m) {
+      const float d = ds[m * 17 + c];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_fmaf(d, xs[m * 65 + 4 * kq + i], acc[i]);
+      accb += d;
+    }
+  }
+  const int n = nb + c;
+  if (n < a.N) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = kb + 4 * kq + i;
+      if (k < a.k_real) a.dw[(size_t)n * a.dw_row + k] += acc[i];
+    }
+    if (a.db && kb == 0 && kq == 0) a.db[n] += accb;
+  }
+}
+
+static int lin_check(const char* who, int M, int K, int N, int xp) {
+  if (M <= 0 || K <= 0 || N <= 0) S2P_FAIL(-1, "%s: empty problem", who);
+  if (K % 4 || xp % 4) S2P_FAIL(-1, "%s: K and pitches must be multiples of 4 floats", who);
+  return 0;
+}
+
+// y[M][y_pitch] = act(x[M][K] . w[N][w_row]^T + bias); columns [N, n_store) are written as zeros (channel padding)
+extern "C" int s2p_linear_fwd(const float* x, int M, int K, int x_pitch, const float* w, int w_row, const float* bias, int N,
+                              int act, float slope, float* y, int y_pitch, int n_store, void* stream) {
+  int rc = lin_check("s2p_linear_fwd", M, K, N, x_pitch); if (rc) return rc;
+  if (!x || !w || !y || w_row % 4 || n_store < N || n_store > y_pitch) S2P_FAIL(-1, "s2p_linear_fwd: bad arguments");
+  LinArgs a{}; a.x = x; a.w = w; a.bias = bias; a.y = y; a.M = M; a.Kr = K; a.N = N; a.x_pitch = x_pitch; a.w_row = w_row;
+  a.y_pitch = y_pitch; a.n_store = n_store; a.act = act; a.slope = slope; a.ksplit = 1; a.k_per_split = K;
+  hipLaunchKernelGGL(lin_fwd_kernel, dim3(cdiv(n_store, 16), cdiv(M, 64), 1), dim3(256), 0, (hipStream_t)stream, a);
+  S2P_CHECK_LAUNCH("lin_fwd_kernel");
+  return 0;
+}
+
+extern "C" size_t s2p_linear_bwd_workspace(int M, int K, int N) {
+  const int ks = N >= 2048 ? cdiv(N, 512) : 1;
+  return ks > 1 ? (size_t)ks * M * ((K + 3) / 4 * 4) * sizeof(float) : 0;
+}
+
+// Backward of y = act(x . w^T + b) given dy = dL/dy and the layer's OUTPUT y (act != NONE):
+//   dw[N][dw_row] += dpre^T x (columns < k_real), db[N] += sum_m dpre, dx[M][dx_pitch] = dpre . w  (dx may be NULL),
+// dpre = dy * act'(y).  w_bwd: [K][wb_row] = the transpose of w (row k holds w[:, k]).
+extern "C" int s2p_linear_bwd(const float* x, int x_pitch, const float* dy, int dy_pitch, const float* y, int y_pitch, int M,
+                              int K, int k_real, int N, const float* w_bwd, int wb_row, int act, float slope, float* dw,
+                              int dw_row, float* db, float* dx, int dx_pitch, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+  int rc = lin_check("s2p_linear_bwd", M, K, N, x_pitch); if (rc) return rc;
+  if (!x || !dy || !dw || dy_pitch % 4 || N % 4) S2P_FAIL(-1, "s2p_linear_bwd: bad arguments (N and pitches must be multiples of 4)");
+  if (act != S2P_ACT_NONE && (!y || y_pitch % 4)) S2P_FAIL(-1, "s2p_linear_bwd: the activation output is needed");
+  if (dx && (!w_bwd || wb_row % 4)) S2P_FAIL(-1, "s2p_linear_bwd: dx needs w_bwd");
+  hipStream_t st = (hipStream_t)stream;
+  LinArgs a{};
+  a.M = M; a.act = act; a.slope = slope;
+  // wgrad part
+  a.xin = x; a.xin_pitch = x_pitch; a.dy = dy; a.dy_pitch = dy_pitch; a.yact = act != S2P_ACT_NONE ? y : nullptr;
+  a.yact_pitch = y_pitch; a.dw = dw; a.dw_row = dw_row; a.db = db; a.K = K; a.k_real = k_real; a.N = N;
+  const int wg_blocks = cdiv(N, 16) * cdiv(K, 64);
+  hipLaunchKernelGGL(lin_wgrad_kernel, dim3(wg_blocks), dim3(256), 0, st, a);
+  S2P_CHECK_LAUNCH("lin_wgrad_kernel");
+  if (!dx) return 0;
+  // dgrad: "x" = dy (with the activation derivative folded in), reduction over N, output columns = the K inputs
+  const int ks = N >= 2048 ? cdiv(N, 512) : 1;
+  LinArgs g = a;
+  g.x = dy; g.x_pitch = dy_pitch; g.xact = a.yact; g.xact_pitch = y_pitch; g.in_act = act; g.w = w_bwd; g.w_row = wb_row;
+  g.bias = nullptr; g.y = dx; g.y_pitch = dx_pitch; g.Kr = N; g.act = S2P_ACT_NONE;
+  const int kcols = (K + 3) / 4 * 4;
+  g.n_store = kcols <= dx_pitch ? kcols : K;
+  g.N = K;
+  if (ks == 1) {
+    g.ksplit = 1; g.k_per_split = g.Kr;
+    hipLaunchKernelGGL(lin_fwd_kernel, dim3(cdiv(g.n_store, 16), cdiv(M, 64), 1), dim3(256), 0, st, g);
+    S2P_CHECK_LAUNCH("lin_fwd_kernel(dgrad)");
+    return 0;
+  }
+  const size_t need = (size_t)ks * M * g.n_store * sizeof(float);
+  if (!workspace || workspace_bytes < need) S2P_FAIL(-1, "s2p_linear_bwd: workspace of %zu bytes needed", need);
+  g.part = (float*)workspace; g.ksplit = ks; g.k_per_split = cdiv(g.Kr, ks); g.k_per_split = (g.k_per_split + 63) / 64 * 64;
+  g.ksplit = cdiv(g.Kr, g.k_per_split);
+  hipLaunchKernelGGL(lin_fwd_kernel, dim3(cdiv(g.n_store, 16), cdiv(M, 64), g.ksplit), dim3(256), 0, st, g);
+  S2P_CHECK_LAUNCH("lin_fwd_kernel(dgrad, split)");
+  hipLaunchKernelGGL(lin_splitk_reduce_kernel, dim3(cdiv((long long)M * g.n_store, 256)), dim3(256), 0, st, g);
+  S2P_CHECK_LAUNCH("lin_splitk_reduce_kernel");
+  return 0;
+}

@@ -180,13 +180,17 @@ class S2PGenerator(BaseNetwork):
         side = self._side_stream()
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            pe_pitch = pad_to(self.state_dim * (1 + 2 * self.L_oct), 4)
-            h = ops.posenc(state.contiguous(), self.L_oct, pe_pitch).view(N, 1, 1, pe_pitch)
+            # dedicated small-M fp32 kernels (csrc/linear_small.hip): one ~4 us launch per layer
+            pe_dim = self.state_dim * (1 + 2 * self.L_oct)
+            pe_pitch = pad_to(pe_dim, 4)
+            h = ops.posenc(state.contiguous(), self.L_oct, pe_pitch)    # [N, pe_pitch]
             hs = [h]
             for i in range(self.n_mlp):
-                h = L[f"fc{i}"].fwd(h, act=ACT_LRELU, slope=LRELU)
+                pk = L[f"fc{i}"].pk
+                h = ops.linear_fwd(h, pk.w_fwd, pk.bias, pk.Cpad, pk.R, ACT_LRELU, LRELU)
                 hs.append(h)
-            st_all = L["fc_state"].fwd(h).view(N, -1)                   # [N, 12*2C] fp32
+            pk = L["fc_state"].pk
+            st_all = ops.linear_fwd(h, pk.w_fwd, pk.bias, pk.Cpad, pk.R)  # [N, 12*2C] fp32
         st_all.record_stream(main)          # allocated on the side stream, consumed by the norms on the main stream
         state.record_stream(side)
         # image conditioning
@@ -289,14 +293,12 @@ class S2PGenerator(BaseNetwork):
         dst_all.record_stream(side)
         with torch.cuda.stream(side):
             hs = ctx["hs"]
-            dstv = dst_all.view(N, 1, 1, -1)
-            L["fc_state"].wgrad(hs[-1], dstv)
-            dh = L["fc_state"].dgrad(dstv, hs[-1].shape)
+            pk = L["fc_state"].pk
+            dh = ops.linear_bwd(hs[-1], dst_all, None, pk.w_bwd, pk.Cpad, pk.C, pk.R, ACT_NONE, 0.0, pk.gw, pk.gb)
             for i in reversed(range(self.n_mlp)):
-                dpre = ops.act_bwd(dh, hs[i + 1], ACT_LRELU, LRELU)
-                L[f"fc{i}"].wgrad(hs[i], dpre)
-                if i > 0:
-                    dh = L[f"fc{i}"].dgrad(dpre, hs[i].shape)
+                pk = L[f"fc{i}"].pk              # LeakyReLU derivative (from the saved output hs[i+1]) folded into the operands
+                dh = ops.linear_bwd(hs[i], dh, hs[i + 1], pk.w_bwd, pk.Cpad, pk.C, pk.R, ACT_LRELU, LRELU, pk.gw, pk.gb,
+                                    need_dx=i > 0)
         # encoder
         for i in reversed(range(self.n_down)):
             xin, x, s, a = ctx["enc"][i + 1]

@@ -246,6 +246,29 @@ def in_bwd(da, x, C, stats, gb=None, gb_off=0, gb_st=None, st_off=0, act=ACT_NON
     return dx
 
 
+def linear_fwd(x, w_fwd, bias, K, N, act=ACT_NONE, slope=0.2, n_store=None):
+    """y = act(x @ w.T + b) for the small fp32 layers of the state path.  x: fp32 [M, x_pitch]; w_fwd: packed
+    [1][N][1][Kpad] fp32 (ParamStore pack); returns fp32 [M, n_store] (columns >= N zero)."""
+    M, xp = x.shape
+    n_store = pad_to(N, 4) if n_store is None else n_store
+    y = torch.empty((M, n_store), dtype=torch.float32, device=x.device)
+    check(lib().s2p_linear_fwd(ptr(x), M, K, xp, ptr(w_fwd), w_fwd.shape[-1], ptr(bias), N, act, slope, ptr(y), n_store,
+                               n_store, stream()), "s2p_linear_fwd")
+    return y
+
+
+def linear_bwd(x, dy, y, w_bwd, K, k_real, N, act, slope, dw, db, need_dx=True):
+    """Backward of linear_fwd: dw += dpre.T @ x, db += dpre.sum(0), returns dx = dpre @ w (or None); dpre = dy * act'(y)."""
+    M, xp = x.shape
+    dx = torch.empty((M, xp), dtype=torch.float32, device=x.device) if need_dx else None
+    need = lib().s2p_linear_bwd_workspace(M, K, N) if need_dx else 0
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
+    check(lib().s2p_linear_bwd(ptr(x), xp, ptr(dy), dy.shape[1], ptr(y), y.shape[1] if y is not None else 0, M, K, k_real, N,
+                               ptr(w_bwd), w_bwd.shape[-1] if w_bwd is not None else 0, act, slope, ptr(dw), k_real, ptr(db),
+                               ptr(dx), xp, ptr(ws), need, stream()), "s2p_linear_bwd")
+    return dx
+
+
 def posenc(state, L, pitch):
     N, S = state.shape
     out = torch.empty((N, pitch), dtype=torch.float32, device=state.device)

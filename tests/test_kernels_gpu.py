@@ -429,3 +429,43 @@ def test_conv_wgrad_head(hip_device, case):
     assert rel_err(db, db0.double() + dy.double().sum()) < 1e-5
     dw2, db2 = run()
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+@pytest.mark.parametrize("case", [(5, 357, 256, True), (64, 256, 6144, False), (130, 40, 72, True), (64, 256, 256, True)])
+def test_linear_small_fwd_bwd(hip_device, case):
+    """State-path linear layers (csrc/linear_small.hip): y = lrelu(x W^T + b), and the backward with the LeakyReLU
+    derivative folded into the operands (dW, db accumulate; dx; the 6144-deep dgrad runs split-K + fixed-order reduce)
+    against float64 autograd at 1e-5; bitwise reproducible."""
+    M, K, N, lrelu = case
+    dev = hip_device
+    g = torch.Generator().manual_seed(K + N)
+    Kp = ops.pad_to(K, 4)
+    x = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / math.sqrt(K); b = torch.randn(N, generator=g)
+    dy = torch.randn(M, N, generator=g)
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    pre = F.linear(xr, wr, br)
+    yr = F.leaky_relu(pre, 0.2) if lrelu else pre
+    yr.backward(dy.double())
+    xp = torch.zeros(M, Kp); xp[:, :K] = x
+    wf = torch.zeros(1, N, 1, Kp); wf[0, :, 0, :K] = w
+    Np = ops.pad_to(N, 4)
+    wb = torch.zeros(1, Kp, 1, Np); wb[0, :K, 0, :N] = w.t()
+    act = ACT_LRELU if lrelu else ACT_NONE
+    y = ops.linear_fwd(xp.to(dev), wf.to(dev), b.to(dev), Kp, N, act, 0.2)
+    torch.cuda.synchronize()
+    assert y.shape == (M, Np) and rel_err(y[:, :N].cpu(), yr.detach()) < 1e-5
+    dw0 = torch.randn(N, K, generator=g); db0 = torch.randn(N, generator=g)
+    dyp = torch.zeros(M, Np); dyp[:, :N] = dy
+
+    def run():
+        dw = dw0.clone().to(dev); db = db0.clone().to(dev)
+        dx = ops.linear_bwd(xp.to(dev), dyp.to(dev), y if lrelu else None, wb.to(dev), Kp, K, N, act, 0.2, dw, db)
+        torch.cuda.synchronize()
+        return dw.cpu(), db.cpu(), dx.cpu()
+
+    dw, db, dx = run()
+    assert rel_err(dw, dw0.double() + wr.grad) < 1e-5
+    assert rel_err(db, db0.double() + br.grad) < 1e-5
+    assert rel_err(dx[:, :K], xr.grad) < 1e-5 and float(dx[:, K:].abs().max() if Kp > K else 0.0) == 0.0
+    dw2, db2, dx2 = run()
+    assert torch.equal(dw, dw2) and torch.equal(db, db2) and torch.equal(dx, dx2)
