@@ -170,65 +170,42 @@ def main():
                 image=(torch.rand(args.batch, 3, args.size, args.size, generator=g) * 2 - 1).to(dev),
                 state=torch.randn(args.batch, opt.state_dim, generator=g).to(dev))
 
-    def g_part():
-        trainer.optimizer_G.zero_grad()
-        g_losses, generated = trainer.pix2pix_model(data, mode="generator")
-        sum(g_losses.values()).mean().backward()
-        trainer.g_losses, trainer.generated = g_losses, generated
-
-    def d_part():
-        trainer.optimizer_D.zero_grad()
-        d_losses = trainer.pix2pix_model(data, mode="discriminator")
-        sum(d_losses.values()).mean().backward()
-        trainer.d_losses = d_losses
-
+    from s2p_amd.stepgraph import StepGraph
     model = trainer.pix2pix_model
-    # The step as five segments; the two all-reduces stay outside the captured graphs (RCCL runs on its own stream).
-    segs = [g_part, lambda: dp.all_reduce_grads(model.netG.store), lambda: (trainer.optimizer_G.step(), d_part()),
-            lambda: dp.all_reduce_grads(model.netD.store), trainer.optimizer_D.step]
-    if world == 1:
-        segs = [lambda: (g_part(), trainer.optimizer_G.step(), d_part(), trainer.optimizer_D.step())]
 
-    def eager_step():
-        for s in segs:
-            s()
+    def train_step():
+        trainer.run_generator_one_step(data)
+        trainer.run_discriminator_one_step(data)
 
-    # warm-up (eager), then optional hipGraph capture of the compute segments
+    # One step = both trainer calls.  It is captured into hipGraph segments by StepGraph: with one rank the whole step is a
+    # single graph; with several ranks the trainer cuts the capture at every collective / event (the tail of the G gradient
+    # is all-reduced under the rest of the G backward, D's all-reduce + Adam run under the next step's generator forward).
     use_graph = not args.no_graph
+    sg = StepGraph(enabled=use_graph)
+    trainer.seg = sg
     for _ in range(max(1, min(args.warmup, 2))):
-        eager_step()
-    torch.cuda.synchronize()
-    graphs = None
+        train_step()
+    trainer.sync(); torch.cuda.synchronize()
     if use_graph:
         try:
-            graphs = []
-            side = torch.cuda.Stream()
-            for i, s in enumerate(segs):
-                if world > 1 and i in (1, 3):
-                    graphs.append(None)
-                    s()
-                    continue
-                gr = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gr, stream=side):
-                    s()
-                graphs.append(gr)
-            torch.cuda.synchronize()
+            sg.capture(train_step)
+            trainer.sync(); torch.cuda.synchronize()
         except Exception as e:     # capture not possible: fall back to eager launches and say so
             if rank == 0:
                 print("hipGraph capture failed (%s); running eager" % str(e).splitlines()[0], file=sys.stderr)
-            graphs = None
+            sg = StepGraph(enabled=False)
+            trainer.seg = sg
             use_graph = False
             torch.cuda.synchronize()
 
     def step():
-        if graphs is None:
-            eager_step()
+        if sg.captured:
+            sg.replay()
         else:
-            for gr, s in zip(graphs, segs):
-                if gr is None:
-                    s()
-                else:
-                    gr.replay()
+            train_step()
+
+    def eager_step():
+        train_step()
 
     for _ in range(args.warmup):
         step()
@@ -236,7 +213,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize(); dp.barrier(); torch.cuda.synchronize()
+    trainer.sync(); torch.cuda.synchronize(); dp.barrier(); torch.cuda.synchronize()
     elapsed = dp.max_over_ranks(time.perf_counter() - t0)
     losses = {k: float(v.detach()) for k, v in trainer.get_latest_losses().items()}
     print("[bench] timed region done: %.3f ms/step" % (elapsed / args.steps * 1e3), file=sys.stderr, flush=True)
@@ -249,7 +226,7 @@ def main():
         # every rank runs the instrumented step (it contains the gradient all-reduces); rank 0 reports
         ops.PROFILE = []
         eager_step()
-        torch.cuda.synchronize()
+        trainer.sync(); torch.cuda.synchronize()
         all_recs, ops.PROFILE = ops.PROFILE, None
     if not args.no_roofline and rank == 0:
         recs = [r for r in all_recs if r["kind"] in ("fwd", "dgrad", "wgrad")]
@@ -300,7 +277,7 @@ def main():
             "config": {"workload": "configs[2]: full G+D train step (hinge GAN + feature matching + VGG19 perceptual "
                                    "+ L1, Adam x2), %dx%d %s, netG=s2p, netD=multiscale(2)" % (args.size, args.size, args.env_type),
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch,
-                       "parallelism": "dp%d" % world, "hip_graph": bool(use_graph),
+                       "parallelism": "dp%d" % world, "hip_graph": bool(use_graph), "graph_segments": sg.n_graphs,
                        "vgg_weights": "seeded stand-in (ImageNet weights unobtainable offline)"},
             "roofline": roofline, "cpu_baseline": cpu, "losses": {k: round(v, 4) for k, v in losses.items()},
         }

@@ -96,6 +96,8 @@ class _GLossNode(torch.autograd.Function):
         dt = fake.dtype
         losses = torch.zeros(4, dtype=torch.float32, device=fake.device)
         x = _build_d_input(model, fake, prev_image, real_image)
+        if model.before_netD is not None:       # data-parallel hook: D's weights of the previous step must have landed
+            model.before_netD()
         res, dctx = model.netD.fwd_nhwc(x)
         num_D = len(res)
         grads = []
@@ -169,6 +171,8 @@ class _DLossNode(torch.autograd.Function):
         N = fake.shape[0]
         losses = torch.zeros(2, dtype=torch.float32, device=fake.device)
         x = _build_d_input(model, fake, prev_image, real_image)
+        if model.before_netD is not None:
+            model.before_netD()
         res, dctx = model.netD.fwd_nhwc(x)
         num_D = len(res)
         grads = []

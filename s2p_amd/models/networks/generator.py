@@ -100,6 +100,15 @@ class S2PGenerator(BaseNetwork):
             setattr(self, f"up{i}", _Conv(c, c // 2, 3, bias=False, transposed=True))
             c //= 2
         self.out = _Conv(c, 3, 7, bias=True)
+        self.on_early_grads = None          # optional callable, see bwd_nhwc
+
+    @property
+    def early_grad_offset(self):
+        """Offset (elements) in the flat parameter / gradient buffers where the early-complete tail starts."""
+        for e in self.store.entries:
+            if e["param"] is self._early_first:
+                return e["offset"]
+        raise RuntimeError("network not finalized")
 
     # ---- flat layout + packed operands ---------------------------------------------------------------------
     def _norms(self):
@@ -132,14 +141,11 @@ class S2PGenerator(BaseNetwork):
         pk = st.pack("mlp_shared_all", [n.mlp_shared.weight for n in norms], [n.mlp_shared.bias for n in norms],
                      dtype=dt, need_bwd=False)
         L["shared"] = ConvLayer(pk, ConvGeom(3, nn_ * nh, 3, 1, 1))
-        for n in norms:
-            st.add(n.mlp_gamma.weight, "conv"); st.add(n.mlp_beta.weight, "conv")
-        for n in norms:
-            st.add(n.mlp_gamma.bias, "bias"); st.add(n.mlp_beta.bias, "bias")
-        pk = st.pack("mlp_gb_all", [w for n in norms for w in (n.mlp_gamma.weight, n.mlp_beta.weight)],
-                     [b for n in norms for b in (n.mlp_gamma.bias, n.mlp_beta.bias)], groups=nn_, dtype=dt)
-        L["gb"] = ConvLayer(pk, ConvGeom(nh, 2 * C, 3, 1, 1, groups=nn_, x_gstride=nh, y_gstride=2 * C))
-        # trunk
+        # encoder.  Flat-buffer order = declaration order, and it is chosen for the data-parallel gradient exchange: the
+        # gradients that the backward finishes LAST (state path, shared conv, stem, down convs: 3 % of the parameters) come
+        # first, everything that is complete once the ResBlk chain and the deferred weight gradients are done (gamma/beta
+        # heads, ResBlk convs, up convs, output conv: 97 %) forms one contiguous tail -> ONE early all-reduce of that tail
+        # overlaps the rest of the backward (Pix2PixTrainer / parallel.py).
         st.add(self.stem.weight, "conv")
         L["stem"] = ConvLayer(st.pack("stem", [self.stem.weight], dtype=dt, need_bwd=False),
                               ConvGeom(3, self.ngf, 7, 1, 3, reflect=True))
@@ -149,6 +155,14 @@ class S2PGenerator(BaseNetwork):
             st.add(d.weight, "conv")
             L[f"down{i}"] = ConvLayer(st.pack(f"down{i}", [d.weight], dtype=dt), ConvGeom(c, 2 * c, 3, 2, 1))
             c *= 2
+        self._early_first = norms[0].mlp_gamma.weight      # first parameter of the early-complete tail
+        for n in norms:
+            st.add(n.mlp_gamma.weight, "conv"); st.add(n.mlp_beta.weight, "conv")
+        for n in norms:
+            st.add(n.mlp_gamma.bias, "bias"); st.add(n.mlp_beta.bias, "bias")
+        pk = st.pack("mlp_gb_all", [w for n in norms for w in (n.mlp_gamma.weight, n.mlp_beta.weight)],
+                     [b for n in norms for b in (n.mlp_gamma.bias, n.mlp_beta.bias)], groups=nn_, dtype=dt)
+        L["gb"] = ConvLayer(pk, ConvGeom(nh, 2 * C, 3, 1, 1, groups=nn_, x_gstride=nh, y_gstride=2 * C))
         for b, blk in enumerate(self.blocks):
             for j, cv in enumerate((blk.conv_0, blk.conv_1)):
                 st.add(cv.weight, "conv"); st.add(cv.bias, "bias")
@@ -284,6 +298,10 @@ class S2PGenerator(BaseNetwork):
         # image-conditioning branch (batched)
         actv, seg = ctx["actv"], ctx["seg"]
         L["gb"].wgrad(actv, dgb_all)
+        # every gradient of the flat buffer's tail [early_grad_offset, end) is final now (data-parallel hook: the trainer
+        # starts that bucket's all-reduce here, under the rest of this backward)
+        if self.on_early_grads is not None:
+            self.on_early_grads()
         d_actv = L["gb"].dgrad(dgb_all, actv.shape, aux=actv, epi=EPI_MUL_ACTGRAD, aux_act=ACT_RELU)
         L["shared"].wgrad(seg, d_actv)
         # state path backward on the side stream, overlapped with the encoder backward below

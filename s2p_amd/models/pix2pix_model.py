@@ -56,6 +56,7 @@ class Pix2PixModel(nn.Module):
         # (loss weights, .mean() over several terms, ...).  Pix2PixTrainer sets it to True because its
         # `sum(losses.values()).mean().backward()` passes exactly 1 to every term, which saves ~12 tiny launches a step.
         self.assume_unit_loss_grad = False
+        self.before_netD = None                 # optional callable run just before netD's forward (data-parallel overlap)
         self.netG, self.netD, self.vgg = self.initialize_networks(opt)
 
     # ---- construction / checkpoint I/O ---------------------------------------------------------------------

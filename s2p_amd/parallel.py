@@ -35,6 +35,28 @@ class DataParallelGroup:
     def all_reduce_grads(self, store):
         return self.all_reduce_(store.grad)
 
+    # ---- overlapped exchange: collectives on a communication stream, ordered against compute with events ---------
+    def comm_stream(self):
+        s = getattr(self, "_comm", None)
+        if s is None:
+            s = self._comm = torch.cuda.Stream()
+        return s
+
+    def all_reduce_async(self, flat):
+        """Sum `flat` over ranks on the communication stream, after everything issued so far on the current stream.
+        Compute issued later on the current stream runs concurrently; call `join()` before it reads `flat`."""
+        if self.world_size <= 1:
+            return
+        comm = self.comm_stream()
+        comm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(comm):
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+
+    def join(self):
+        """Make the current stream wait for everything issued on the communication stream."""
+        if self.world_size > 1:
+            torch.cuda.current_stream().wait_stream(self.comm_stream())
+
     def broadcast_store(self, store, src=0):
         """Make every rank start from rank `src`'s parameters (C2 in SURVEY.md section 2.2)."""
         if self.world_size > 1:

@@ -1,9 +1,22 @@
 """Pix2PixTrainer (SPADE lineage): `run_generator_one_step` / `run_discriminator_one_step`, LR schedule, save.
 
-MI355X-first data parallelism: one process per GPU; after each backward the network's whole flat gradient buffer is
-averaged with ONE RCCL all-reduce (s2p_amd.parallel), then one fused Adam launch.  No DataParallel wrapper.
+MI355X-first data parallelism: one process per GPU; the network's whole gradient lives in ONE flat buffer, so the
+exchange is a couple of large RCCL all-reduces per step (xGMI is point-to-point: few large messages use every link),
+followed by one fused Adam launch.  No DataParallel wrapper, no per-tensor buckets.  With more than one rank the
+collectives run on a communication stream and are hidden under compute:
+
+  * G step: the flat G buffer is laid out so that the 97 % of the gradient that is final once the ResBlk chain and the
+    deferred weight gradients are done is one contiguous tail; its all-reduce starts there (a hook inside the generator's
+    backward) and runs under the rest of the backward (gamma/beta dgrad, shared conv, encoder, state path); only the
+    small head of the buffer is reduced after the backward;
+  * D step: all-reduce + Adam + weight repack of D run entirely on the communication stream, under the NEXT step's
+    generator forward; the next G step waits for them right before its first use of D (a hook in the G-loss node).
+
+`seg` (optional `StepGraph`): when the step is captured into hipGraphs, every collective / event / cross-stream wait
+is a `cut` point between graph segments; in eager mode a cut just runs its action.
 """
 import torch
+import torch.distributed as dist
 
 from ..models.pix2pix_model import Pix2PixModel
 from .. import parallel
@@ -17,6 +30,8 @@ class Pix2PixTrainer:
         # both steps below call sum(losses).mean().backward(): every loss term's upstream gradient is exactly 1
         self.pix2pix_model.assume_unit_loss_grad = True
         self.generated = None
+        self.seg = None
+        self._eD = None                 # event: D's all-reduce + Adam + repack of the previous step are done
         self.dp = parallel.DataParallelGroup.from_env()
         if opt.isTrain:
             self.dp.broadcast_store(self.pix2pix_model.netG.store)
@@ -30,14 +45,59 @@ class Pix2PixTrainer:
             self.pix2pix_model.iters_done = int(ck.get("iters_done", 0)) if ck is not None else 0
             g_lr = self.optimizer_G.param_groups[0]["lr"]
             self.old_lr = g_lr if opt.no_TTUR else g_lr * 2
+            if self.dp.world_size > 1:
+                self.pix2pix_model.netG.on_early_grads = self._allreduce_G_tail
         self.g_losses, self.d_losses = {}, {}
 
+    # ---- cut points (collectives, events, cross-stream waits stay outside captured graphs) --------------------------------
+    def _cut(self, action):
+        if self.seg is not None:
+            self.seg.cut(action)
+        else:
+            action()
+
+    def _wait_D_update(self):
+        def act():
+            if self._eD is not None:
+                torch.cuda.current_stream().wait_event(self._eD)
+        self._cut(act)
+
+    def _allreduce_G_tail(self):
+        net = self.pix2pix_model.netG
+        tail = net.store.grad[net.early_grad_offset:]
+        self._cut(lambda: self.dp.all_reduce_async(tail))
+
+    def _finish_G_exchange(self):
+        net = self.pix2pix_model.netG
+        head = net.store.grad[:net.early_grad_offset]
+
+        def act():
+            self.dp.all_reduce_async(head)
+            self.dp.join()
+        self._cut(act)
+
+    def _finish_D_async(self):
+        """All-reduce, Adam and repack of D on the communication stream; `_eD` marks their completion."""
+        comm = self.dp.comm_stream()
+        comm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(comm):
+            dist.all_reduce(self.pix2pix_model.netD.store.grad, op=dist.ReduceOp.SUM, group=self.dp.group)
+            self.optimizer_D.step()
+            ev = torch.cuda.Event()
+            ev.record(comm)
+        self._eD = ev
+
+    # ---- the two steps ---------------------------------------------------------------------------------------------------
     def run_generator_one_step(self, data):
+        multi = self.dp.world_size > 1
         self.optimizer_G.zero_grad()
+        self.pix2pix_model.before_netD = self._wait_D_update if multi else None
         g_losses, generated = self.pix2pix_model(data, mode="generator")
+        self.pix2pix_model.before_netD = None
         g_loss = sum(g_losses.values()).mean()
-        g_loss.backward()
-        self.dp.all_reduce_grads(self.pix2pix_model.netG.store)
+        g_loss.backward()                  # multi-rank: the tail all-reduce is launched from inside (on_early_grads)
+        if multi:
+            self._finish_G_exchange()
         self.optimizer_G.step()
         self.g_losses = g_losses
         self.generated = generated
@@ -47,9 +107,15 @@ class Pix2PixTrainer:
         d_losses = self.pix2pix_model(data, mode="discriminator")
         d_loss = sum(d_losses.values()).mean()
         d_loss.backward()
-        self.dp.all_reduce_grads(self.pix2pix_model.netD.store)
-        self.optimizer_D.step()
+        if self.dp.world_size > 1:
+            self._cut(self._finish_D_async)
+        else:
+            self.optimizer_D.step()
         self.d_losses = d_losses
+
+    def sync(self):
+        """Wait (on the current stream) for everything the trainer has in flight on the communication stream."""
+        self.dp.join()
 
     def get_latest_losses(self):
         return {**self.g_losses, **self.d_losses}
@@ -58,6 +124,7 @@ class Pix2PixTrainer:
         return self.pix2pix_model.generated_to_nchw(self.generated)
 
     def save(self, epoch):
+        self.sync()
         if self.dp.rank == 0:
             self.pix2pix_model.save(epoch)
 
@@ -68,6 +135,7 @@ class Pix2PixTrainer:
 
     def update_learning_rate(self, epoch):
         opt = self.opt
+        self.sync()                         # the D optimizer may still be stepping on the communication stream
         if epoch > opt.niter:
             lrd = opt.lr / max(opt.niter_decay, 1)
             new_lr = max(self.old_lr - lrd, 0.0)

@@ -41,6 +41,7 @@ def main():
     model.netG.store.master.copy_(w0.to(model.netG.store.master.device))
     model.netG.store.repack()
     tr.run_discriminator_one_step(data)
+    tr.sync()                                               # D's all-reduce + Adam run on the communication stream
     gD = (model.netD.store.grad * tr.optimizer_D.grad_scale).detach().cpu().clone()
     torch.cuda.synchronize()
     losses = {k: float(v) for k, v in tr.get_latest_losses().items()}

@@ -65,3 +65,21 @@ def test_two_ranks_half_batches_equal_one_rank_full_batch(hip_device, tmp_path):
     for k, v in single["losses"].items():
         avg = 0.5 * (r0["losses"][k] + r1["losses"][k])
         assert abs(avg - v) <= 1e-4 * max(abs(v), 1e-2), (k, avg, v)
+
+
+def test_bench_two_ranks_segmented_graphs_rehearsal(hip_device, tmp_path):
+    """bench.py's N>1 path end to end on one GPU: 2 ranks (gloo transport, both on GPU 0) run the overlapped trainer inside
+    StepGraph capture -- the step is cut into several hipGraph segments at the collectives -- and replay it; rank 0 prints the
+    contract JSON line.  (The driver runs the same code with RCCL, one GPU per rank.)"""
+    import json
+    root = os.path.dirname(HERE)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo",
+           "--steps", "3", "--warmup", "1", "--batch", "4", "--no-cpu-baseline", "--no-roofline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["config"]["global_batch"] == 8
+    assert out["config"]["hip_graph"] is True and out["config"]["graph_segments"] >= 4, out["config"]
+    assert all(v == v for v in out["losses"].values())

@@ -17,15 +17,41 @@ def main(args=None):
     dl = create_dataloader(opt, trainer.dp.rank, trainer.dp.world_size)
     total_epochs = opt.niter + opt.niter_decay
     it = trainer.pix2pix_model.iters_done                 # > 0 when resuming with --continue_train
+    # --hip_graph: the G+D step is captured once into hipGraph segments (s2p_amd/stepgraph.py) and replayed; each batch is
+    # copied into static device buffers first.  The capture bakes the learning rate in, so it is redone when the rate changes.
+    sg, static, captured_lr = None, None, None
     for epoch in range(trainer.first_epoch, total_epochs + 1):
         if hasattr(dl.sampler, "set_epoch"):
             dl.sampler.set_epoch(epoch)
         t0 = time.time()
         for i, data in enumerate(dl):
             it += 1
-            if i % opt.D_steps_per_G == 0:
-                trainer.run_generator_one_step(data)
-            trainer.run_discriminator_one_step(data)
+            if opt.hip_graph and opt.D_steps_per_G == 1:
+                from s2p_amd.stepgraph import StepGraph
+                dev = trainer.pix2pix_model.device
+                if static is None:
+                    static = {k: data[k].to(dev, torch.float32).contiguous().clone() for k in ("prev_image", "state", "image")}
+                for k in static:
+                    static[k].copy_(data[k], non_blocking=True)
+                if sg is None or captured_lr != trainer.old_lr:
+                    def train_step():
+                        trainer.run_generator_one_step(static)
+                        trainer.run_discriminator_one_step(static)
+                    if sg is None:
+                        train_step()                       # one eager step first (allocator / library warm-up)
+                        it += 1
+                        for k in static:
+                            static[k].copy_(data[k], non_blocking=True)
+                    sg = StepGraph()
+                    trainer.seg = sg
+                    sg.capture(train_step)                 # runs the step once for real while capturing
+                    captured_lr = trainer.old_lr
+                else:
+                    sg.replay()
+            else:
+                if i % opt.D_steps_per_G == 0:
+                    trainer.run_generator_one_step(data)
+                trainer.run_discriminator_one_step(data)
             if it % opt.print_freq == 0 and trainer.dp.rank == 0:
                 losses = {k: float(v) for k, v in trainer.get_latest_losses().items()}
                 print("(epoch %d, iters %d) " % (epoch, it) + " ".join("%s: %.3f" % kv for kv in losses.items()))
