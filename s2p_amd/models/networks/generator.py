@@ -155,7 +155,7 @@ class S2PGenerator(BaseNetwork):
             st.add(d.weight, "conv")
             L[f"down{i}"] = ConvLayer(st.pack(f"down{i}", [d.weight], dtype=dt), ConvGeom(c, 2 * c, 3, 2, 1))
             c *= 2
-        self._early_first = norms[0].mlp_gamma.weight      # first parameter of the early-complete tail
+        self.__dict__["_early_first"] = norms[0].mlp_gamma.weight      # first parameter of the early-complete tail (not a module attribute: keeps state_dict clean)
         for n in norms:
             st.add(n.mlp_gamma.weight, "conv"); st.add(n.mlp_beta.weight, "conv")
         for n in norms:

@@ -506,3 +506,30 @@ def test_simple_test_cli_seq_len_5(hip_device, tmp_path):
     ref = O.rollout(sd, frames[:1], states[1:].unsqueeze(0), O.Spec(state_dim=opt.state_dim))[0]
     again = simple_test.rollout(model.netG, frames[:1], states[1:].unsqueeze(0))[0].cpu()
     assert rel(again, ref) < 1e-4
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_train_cli_epochs_checkpoint_and_resume(hip_device, tmp_path, graph):
+    """train.py (README.md:59) on the shipped tiny dataset: two epochs, checkpoints <env>_<epoch>.pth + latest, then
+    --continue_train resumes at epoch 3 with the restored optimizer state; with --hip_graph the step runs
+    from the captured StepGraph."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import train
+    base = ["--env_type=cheetah", "--dataroot=" + os.path.join(root, "datasets"), "--netG=s2p", "--batchSize=2", "--gpu_ids=0",
+            "--checkpoints_dir", str(tmp_path), "--save_epoch_freq", "1", "--print_freq", "1", "--no_vgg_loss"]
+    if graph:
+        base.append("--hip_graph")
+    train.main(base + ["--niter", "2"])
+    ck = torch.load(os.path.join(str(tmp_path), "cheetah_2.pth"), map_location="cpu")
+    assert ck["epochs_done"] == 2 and ck["iters_done"] > 0 and "optG" in ck
+    assert os.path.exists(os.path.join(str(tmp_path), "cheetah_latest.pth"))
+    step2 = int(ck["optG"]["step"])
+    train.main(base + ["--niter", "3", "--continue_train"])
+    ck3 = torch.load(os.path.join(str(tmp_path), "cheetah_3.pth"), map_location="cpu")
+    assert ck3["epochs_done"] == 3 and int(ck3["optG"]["step"]) > step2
+    assert not torch.equal(ck3["netG"]["out.weight"], ck["netG"]["out.weight"])
+    with pytest.raises(FileNotFoundError):
+        train.main(["--env_type=walker", "--dataroot=" + os.path.join(root, "datasets"), "--gpu_ids=0", "--checkpoints_dir",
+                    str(tmp_path), "--continue_train"])
