@@ -415,9 +415,21 @@ __global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, lo
   const float lr_bc1 = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
   GRID_STRIDE(idx, n4) {
     long long i = idx * 4;
-    long long e1 = i + 4 <= n ? 4 : n - i;
-    for (long long e = 0; e < e1; ++e) {
-      long long k = i + e;
+    if (i + 4 <= n) {                       // 16-byte accesses: 28 B / parameter at HBM speed (4-byte accesses ran at 2.6 TB/s)
+      const f32x4 g4 = *(const f32x4*)(g + i);
+      f32x4 m4 = *(const f32x4*)(m + i), v4 = *(const f32x4*)(v + i), p4 = *(const f32x4*)(p + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float gg = g4[e] * gscale;
+        const float mm = beta1 * m4[e] + (1.f - beta1) * gg;
+        const float vv = beta2 * v4[e] + (1.f - beta2) * gg * gg;
+        m4[e] = mm; v4[e] = vv;
+        p4[e] -= lr_bc1 * mm / (sqrtf(vv) * inv_sqrt_bc2 + eps);
+      }
+      *(f32x4*)(m + i) = m4; *(f32x4*)(v + i) = v4; *(f32x4*)(p + i) = p4;
+      continue;
+    }
+    for (long long k = i; k < n; ++k) {
       float gg = g[k] * gscale;
       float mm = beta1 * m[k] + (1.f - beta1) * gg;
       float vv = beta2 * v[k] + (1.f - beta2) * gg * gg;
