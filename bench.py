@@ -253,11 +253,31 @@ def main():
         dominant = dict(kind=dk, shape_N_H_W_Cin_Cout_k_stride_groups_transposed=list(dshape), launches_per_step=dv[2],
                         avg_launch_us=round(dv[1] * 1e3 / dv[2], 2), gflop_per_launch=round(dv[0] / dv[2] / 1e9, 2),
                         tflops=round(dv[0] / (dv[1] * 1e-3) / 1e12, 2), frac=round(dv[0] / (dv[1] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4))
+        # HBM traffic of the dominant launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE in separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md): counters cannot be collected from
+        # inside this process, so the latest committed measurement of the same kernel + grid is reported, with its source
+        traffic, traffic_detail = None, None
+        try:
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_traffic.json")))
+            if cands:
+                tj = json.load(open(cands[-1]))
+                want_grid = str(((args.batch * (args.size // 4) ** 2 + 127) // 128) * 2 * 256)
+                for k, v in tj.items():
+                    if k.startswith("conv_halo_kernel") and ("grid %s " % want_grid) in k and "hbm_read_bytes" in v:
+                        traffic = int(v["hbm_read_bytes"] + v["hbm_write_bytes"])          # HBM bytes per launch of the dominant kernel
+                        traffic_detail = dict(hbm_read_mb=round(v["hbm_read_bytes"] / 1e6, 2), hbm_write_mb=round(v["hbm_write_bytes"] / 1e6, 2),
+                                       algorithmic_mb=round((args.batch * (args.size // 4) ** 2 * 256 * 2 * 2 + 256 * 2304 * 2) / 1e6, 2),
+                                       mfma_busy_share=round(v.get("mfma_util", 0.0), 4), launches_profiled=v.get("launches"),
+                                       source=os.path.relpath(cands[-1], ROOT) + " :: " + k)
+                        break
+        except Exception as e:      # evidence file unreadable: report null rather than fail the bench
+            print("[bench] traffic: %s" % e, file=sys.stderr)
         roofline = dict(bound="mfma", kernel="implicit-GEMM conv family: conv_halo/conv_dma/conv_gather (fwd, dgrad) + wgrad_dma/wgrad "
                                              "+ thin_tiled kernels, all %d launches of one step" % len(recs),
                         dominant_layer=dominant, spade_resblk_fwd_bwd=resblk,
                         achieved=round(ach, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                        traffic=None, algorithmic_gflop_per_step=round(tot_f / 1e9, 1), conv_ms_per_step=round(tot_ms, 3),
+                        traffic=traffic, traffic_detail=traffic_detail, algorithmic_gflop_per_step=round(tot_f / 1e9, 1), conv_ms_per_step=round(tot_ms, 3),
                         avg_launch_us=round(tot_ms * 1e3 / max(len(recs), 1), 2),
                         by_kind={k: dict(gflop=round(v[0] / 1e9, 1), ms=round(v[1], 3), launches=v[2],
                                          tflops=round(v[0] / (v[1] * 1e-3) / 1e12, 2)) for k, v in by_kind.items()})

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define S2P_VERSION 104
+#define S2P_VERSION 105
 
 enum { S2P_F32 = 0, S2P_BF16 = 1 };
 enum { S2P_ACT_NONE = 0, S2P_ACT_RELU = 1, S2P_ACT_LRELU = 2, S2P_ACT_TANH = 3, S2P_ACT_SWISH = 4 };
@@ -143,6 +143,13 @@ int s2p_in_bwd_apply(int dtype, const void* da, int da_pitch, const void* x, int
 /* out[n][0:S]=s, then for k<L: sin(2^k s), cos(2^k s); columns >= S*(1+2L) up to out_pitch
  * are zero-filled.  fp32 in / fp32 out.                                                 */
 int s2p_posenc_fwd(const float* state, int N, int S, int L, float* out, int out_pitch, void* stream);
+
+/* s2p_in_bwd_reduce + s2p_in_bwd_apply in one call (one fused launch for planes of at most 512 (bf16) / 256 (fp32) pixels with
+ * relu / lrelu / no activation; otherwise the two kernels, which need `sums`).                                             */
+int s2p_in_norm_bwd(int dtype, const void* da, int da_pitch, const void* x, int N, int HW, int C, int pitch,
+                    const float* stats, const void* gb_img, int gb_pitch, const float* gb_st, int gb_st_pitch,
+                    int act, float slope, float eps, float* sums, void* dx, int dx_pitch, void* dgb_img,
+                    int dgb_pitch, float* dgb_st, int dgb_st_pitch, void* stream);
 
 /* Small fp32 linear layers of the state path (replaces F.linear + LeakyReLU and their autograd backward for the
  * StateMapping MLP and the per-norm state affine; batch M of a few dozen rows: latency-bound, csrc/linear_small.hip).

@@ -58,6 +58,8 @@ SIGNATURES = {
                           c_float, c_float, _P, _P],
     "s2p_in_bwd_apply": [c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, c_int,
                          c_float, c_float, _P, _P, c_int, _P, c_int, _P, c_int, _P],
+    "s2p_in_norm_bwd": [c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, c_int,
+                        c_float, c_float, _P, _P, c_int, _P, c_int, _P, c_int, _P],
     "s2p_in_stats_floats": [c_int, c_int, c_int],
     "s2p_in_bwd_sums_floats": [c_int, c_int, c_int],
     "s2p_linear_fwd": [_P, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, c_float, _P, c_int, c_int, _P],
@@ -115,7 +117,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the export is missing
             fn.argtypes = args
             fn.restype = _RESTYPE.get(name, c_int)
-        if L.s2p_version() < 104:
+        if L.s2p_version() < 105:
             raise RuntimeError("libs2p_hip.so is older than this package")
         _lib = L
     return _lib

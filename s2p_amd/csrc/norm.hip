@@ -277,16 +277,18 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const NormArgs a) {
 // (mean, then centred second moment) with wave shuffles + LDS, and applies the modulation from registers: x is read
 // once instead of twice and the statistics pass is not a separate launch.  It also writes the statistics buffer in
 // the usual self-describing format (one split), so the backward kernels consume it unchanged.
-template <typename T>
+template <typename T, int CS>          // CS = channels per workgroup: 64 (full 128-byte bf16 lines) or 32 (twice the workgroups)
 __global__ __launch_bounds__(1024) void in_fused_fwd_kernel(const NormArgs a) {
   constexpr int CE = DT<T>::CE;
-  constexpr int CS = 64, NCH = CS / CE, PR = 1024 / NCH, MAXP = 4;     // bf16: 128 pixel rows x 4 = 512 pixels; fp32: 64 x 4
-  constexpr int RPW = 64 / NCH;                                        // pixel rows held by one wave: 8 / 4
+  constexpr int NCH = CS / CE, PR = 1024 / NCH, MAXP = (DT<T>::CE == 8 ? 512 : 256) / PR;   // planes of <= 512 (bf16) / 256 (fp32) pixels
+  constexpr int RPW = 64 / NCH;
   __shared__ float red[16][CS];
   __shared__ float cst[4][CS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cc = tid % NCH, pr = tid / NCH;
-  const int n = blockIdx.y, c0 = blockIdx.x * CS + cc * CE;
+  // grid = (images, slabs), images fastest: the workgroups of neighbouring slabs of one image are N apart in dispatch
+  // order, i.e. on the same XCD when N % 8 == 0 -- with CS = 32 the two halves of a 128-byte line meet in one L2
+  const int n = blockIdx.x, slab = blockIdx.y, c0 = slab * CS + cc * CE;
   const bool cok = c0 < a.C;
   const size_t img = (size_t)n * a.HW;
   const T* xb = (const T*)a.x + img * a.x_pitch + c0;
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(1024) void in_fused_fwd_kernel(const NormArgs a) {
   }
   plane_sum(acc, 1);
   if (tid < CS) {
-    const int c = blockIdx.x * CS + tid;
+    const int c = slab * CS + tid;
     if (c < a.C) {
       float* o = (float*)a.stats + STATS_HDR + ((size_t)n * a.C + c) * 2;
       o[0] = cst[0][tid] * inv; o[1] = cst[1][tid];
@@ -378,6 +380,125 @@ __global__ __launch_bounds__(1024) void in_fused_fwd_kernel(const NormArgs a) {
       o0.set(e, act_generic ? act_fwd(yv, a.act, a.slope) : (yv > 0.f ? yv : yv * ns));
     }
     *(u32x4*)(yb + (size_t)p * a.y_pitch) = o0.raw;
+  }
+}
+
+// Fused backward for small planes, same geometry as in_fused_fwd_kernel: one workgroup of 1024 threads owns an (image,
+// 64-channel slab) plane, loads x, dL/dy, gamma, beta once (64 VGPRs of 16-byte chunks per thread), forms the four plane
+// sums (wave shuffles + LDS, fixed order) and then writes dx, d(gamma_img | beta_img) and the state-affine gradient from
+// the registers: one launch and one read of every tensor instead of the reduce + apply pair (each tensor read twice).
+// Per-channel constants stay in LDS and are re-read per use (keeps the kernel under the 128-VGPR budget of 16 waves / CU).
+template <typename T, int CS>
+__global__ __launch_bounds__(1024) void in_fused_bwd_kernel(const NormArgs a) {
+  constexpr int CE = DT<T>::CE;
+  constexpr int NCH = CS / CE, PR = 1024 / NCH, MAXP = (DT<T>::CE == 8 ? 512 : 256) / PR;
+  __shared__ float red[4][16][CS];
+  __shared__ __attribute__((aligned(16))) float cst[6][CS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cc = tid % NCH, pr = tid / NCH;
+  const int n = blockIdx.x, slab = blockIdx.y, c0 = slab * CS + cc * CE;       // images fastest: see in_fused_fwd_kernel
+  const bool cok = c0 < a.C;
+  // workgroup-uniform bases (SGPRs) + 32-bit per-lane element offsets: 64-bit per-lane addresses for 4 pixels x 7 tensors
+  // would not fit the register budget (the plane of one image is far below 2^31 elements)
+  const size_t img = (size_t)n * a.HW;
+  const int cb0 = slab * CS;
+  const T* xb = (const T*)a.x + img * a.x_pitch + cb0;
+  const T* dab = (const T*)a.da + img * a.da_pitch + cb0;
+  const T* gbb = a.gb ? (const T*)a.gb + img * a.gb_pitch + cb0 : nullptr;
+  const int lc = cc * CE;
+  Chunk<T> xv[MAXP], dv[MAXP], gv[MAXP], bv[MAXP];
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) {
+    const int p = pr + k * PR;
+    xv[k].raw = (u32x4){0u, 0u, 0u, 0u}; dv[k].raw = xv[k].raw; gv[k].raw = xv[k].raw; bv[k].raw = xv[k].raw;
+    if (cok && p < a.HW) {
+      xv[k].raw = *(const u32x4*)(xb + (p * a.x_pitch + lc));
+      dv[k].raw = *(const u32x4*)(dab + (p * a.da_pitch + lc));
+      if (gbb) { gv[k].raw = *(const u32x4*)(gbb + (p * a.gb_pitch + lc)); bv[k].raw = *(const u32x4*)(gbb + (p * a.gb_pitch + lc + a.C)); }
+    }
+  }
+  if (tid < CS) {
+    const int c = slab * CS + tid;
+    float m = 0.f, r = 0.f, g1 = 1.f, b1 = 0.f;
+    if (c < a.C) {
+      mean_rstd(a, n, c, m, r);
+      if (a.gbst) { g1 = 1.f + a.gbst[(size_t)n * a.gbst_pitch + c]; b1 = a.gbst[(size_t)n * a.gbst_pitch + a.C + c]; }
+    }
+    cst[0][tid] = m; cst[1][tid] = r; cst[2][tid] = g1; cst[3][tid] = b1;
+  }
+  __syncthreads();
+  const float gneg = a.act == S2P_ACT_RELU ? 0.f : (a.act == S2P_ACT_LRELU ? a.slope : 1.f);
+  unsigned posmask = 0u;
+  // ---- pass 1: plane sums.  Pixels beyond HW were loaded as zeros: their dL/dy is 0, so they add nothing.
+#pragma unroll
+  for (int e = 0; e < CE; ++e) {
+    const int ch = cc * CE + e;
+    const float m = cst[0][ch], r = cst[1][ch], g1 = cst[2][ch], b1 = cst[3][ch];
+    float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+      const float gg = g1 + (gbb ? gv[k].get(e) : 0.f), bb = b1 + (gbb ? bv[k].get(e) : 0.f);
+      float xh;
+      const float yv = mat_value(xv[k].get(e), m, r, gg, bb, xh);
+      const bool pos = yv > 0.f;
+      posmask |= pos ? (1u << (k * CE + e)) : 0u;           // pass 2 takes the branch from here: beta is dead after pass 1
+      const float dy = dv[k].get(e) * (pos ? 1.f : gneg);
+      const float dxh = dy * gg;
+      q0 += dxh; q1 += dxh * xh; q2 += dy * xh; q3 += dy;
+    }
+#pragma unroll
+    for (int o = NCH; o < 64; o <<= 1) {
+      q0 += __shfl_xor(q0, o, 64); q1 += __shfl_xor(q1, o, 64); q2 += __shfl_xor(q2, o, 64); q3 += __shfl_xor(q3, o, 64);
+    }
+    if (lane < NCH) { red[0][wave][ch] = q0; red[1][wave][ch] = q1; red[2][wave][ch] = q2; red[3][wave][ch] = q3; }
+    __builtin_amdgcn_sched_barrier(0);        // one channel at a time: interleaving the unrolled channels spills (128-VGPR budget)
+  }
+  __syncthreads();
+  if (tid < CS) {
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { t0 += red[0][w][tid]; t1 += red[1][w][tid]; t2 += red[2][w][tid]; t3 += red[3][w][tid]; }
+    const float inv = 1.f / (float)a.HW;
+    cst[4][tid] = t0 * inv; cst[5][tid] = t1 * inv;
+    const int c = slab * CS + tid;
+    if (a.dgbst && c < a.C) {
+      a.dgbst[(size_t)n * a.dgbst_pitch + c] = t2;
+      a.dgbst[(size_t)n * a.dgbst_pitch + a.C + c] = t3;
+    }
+  }
+  __syncthreads();
+  if (!cok) return;
+  // ---- pass 2: outputs, pixel by pixel, four channels at a time (constants re-read from LDS as float4)
+  T* yb = (T*)a.y + img * a.y_pitch + cb0;
+  T* dgb = a.dgb ? (T*)a.dgb + img * a.dgb_pitch + cb0 : nullptr;
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) {
+    const int p = pr + k * PR;
+    if (p >= a.HW) break;
+    Chunk<T> o0, o1, o2;
+#pragma unroll
+    for (int h4 = 0; h4 < CE / 4; ++h4) {
+      const int ch = cc * CE + 4 * h4;
+      const f32x4 m4 = *(const f32x4*)&cst[0][ch], r4 = *(const f32x4*)&cst[1][ch], g4 = *(const f32x4*)&cst[2][ch],
+                  s14 = *(const f32x4*)&cst[4][ch], s24 = *(const f32x4*)&cst[5][ch];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = 4 * h4 + j;
+        const float gg = g4[j] + (gbb ? gv[k].get(e) : 0.f);
+        const float xh = (xv[k].get(e) - m4[j]) * r4[j];
+        const float dy = dv[k].get(e) * (((posmask >> (k * CE + e)) & 1u) ? 1.f : gneg);
+        const float dxh = dy * gg;
+        o0.set(e, r4[j] * (dxh - s14[j] - xh * s24[j]));
+        o1.set(e, dy * xh);
+        o2.set(e, dy);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    *(u32x4*)(yb + (p * a.y_pitch + lc)) = o0.raw;
+    if (dgb) {
+      *(u32x4*)(dgb + (p * a.dgb_pitch + lc)) = o1.raw;
+      *(u32x4*)(dgb + (p * a.dgb_pitch + lc + a.C)) = o2.raw;
+    }
   }
 }
 
@@ -492,9 +613,15 @@ extern "C" int s2p_in_norm_fwd(int dtype, const void* x, int N, int HW, int C, i
   NormArgs a{}; a.x = x; a.stats = stats; a.gb = gb_img; a.gbst = gb_st; a.y = y;
   a.N = N; a.HW = HW; a.C = C; a.x_pitch = pitch; a.gb_pitch = gb_pitch; a.gbst_pitch = gb_st_pitch;
   a.y_pitch = y_pitch; a.act = act; a.slope = slope; a.eps = eps;
-  dim3 grid(cdiv(C, 64), N);
-  if (dtype == S2P_F32) hipLaunchKernelGGL(in_fused_fwd_kernel<float>, grid, dim3(1024), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(in_fused_fwd_kernel<__bf16>, grid, dim3(1024), 0, (hipStream_t)stream, a);
+  // 32-channel slabs (twice the workgroups, two per CU) were measured and lost: 24.2 vs 20.5 us on the MAT norms -- the
+  // 64-byte half-line accesses cost more than the extra overlap buys.  Kept selectable in the diagnostics build only.
+  const bool half = s2p_env_set("S2P_NORM_CS32") && C % 32 == 0;
+  dim3 grid(N, cdiv(C, half ? 32 : 64));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == S2P_F32) { if (half) hipLaunchKernelGGL((in_fused_fwd_kernel<float, 32>), grid, dim3(1024), 0, st, a);
+                          else hipLaunchKernelGGL((in_fused_fwd_kernel<float, 64>), grid, dim3(1024), 0, st, a); }
+  else { if (half) hipLaunchKernelGGL((in_fused_fwd_kernel<__bf16, 32>), grid, dim3(1024), 0, st, a);
+         else hipLaunchKernelGGL((in_fused_fwd_kernel<__bf16, 64>), grid, dim3(1024), 0, st, a); }
   S2P_CHECK_LAUNCH("in_fused_fwd_kernel");
   return 0;
 }
@@ -525,6 +652,40 @@ extern "C" int s2p_in_bwd_apply(int dtype, const void* da, int da_pitch, const v
   a.gbst_pitch = gb_st_pitch; a.y_pitch = dx_pitch; a.dgb_pitch = dgb_pitch; a.act = act; a.slope = slope;
   a.eps = eps;
   return launch_apply<1>(dtype, a, (hipStream_t)stream);
+}
+
+// reduce + apply in one call: one fused launch for small planes (relu / lrelu / no activation), else the two kernels
+extern "C" int s2p_in_norm_bwd(int dtype, const void* da, int da_pitch, const void* x, int N, int HW, int C, int pitch,
+                               const float* stats, const void* gb_img, int gb_pitch, const float* gb_st, int gb_st_pitch,
+                               int act, float slope, float eps, float* sums, void* dx, int dx_pitch, void* dgb_img,
+                               int dgb_pitch, float* dgb_st, int dgb_st_pitch, void* stream) {
+  int rc = norm_check("s2p_in_norm_bwd", dtype, C, pitch, gb_pitch, da_pitch); if (rc) return rc;
+  const int maxhw = dtype == S2P_F32 ? 256 : 512;
+  const bool simple_act = act == S2P_ACT_NONE || act == S2P_ACT_RELU || act == S2P_ACT_LRELU;
+  if (HW > maxhw || !simple_act || s2p_env_set("S2P_NO_FUSED_NORM")) {
+    if (!sums) S2P_FAIL(-1, "s2p_in_norm_bwd: the two-kernel path needs the `sums` workspace");
+    rc = s2p_in_bwd_reduce(dtype, da, da_pitch, x, N, HW, C, pitch, stats, gb_img, gb_pitch, gb_st, gb_st_pitch, act, slope, eps,
+                           sums, stream);
+    if (rc) return rc;
+    return s2p_in_bwd_apply(dtype, da, da_pitch, x, N, HW, C, pitch, stats, gb_img, gb_pitch, gb_st, gb_st_pitch, act, slope, eps,
+                            sums, dx, dx_pitch, dgb_img, dgb_pitch, dgb_st, dgb_st_pitch, stream);
+  }
+  if (dx_pitch % (dtype == S2P_F32 ? 4 : 8) || dgb_pitch % (dtype == S2P_F32 ? 4 : 8))
+    S2P_FAIL(-1, "s2p_in_norm_bwd: bad output pitch");
+  if (dgb_st && dgb_st_pitch < 2 * C) S2P_FAIL(-1, "s2p_in_norm_bwd: dgb_st pitch < 2*C");
+  NormArgs a{}; a.x = x; a.da = da; a.stats = stats; a.gb = gb_img; a.gbst = gb_st;
+  a.y = dx; a.dgb = dgb_img; a.dgbst = dgb_st; a.dgbst_pitch = dgb_st_pitch;
+  a.N = N; a.HW = HW; a.C = C; a.x_pitch = pitch; a.da_pitch = da_pitch; a.gb_pitch = gb_pitch;
+  a.gbst_pitch = gb_st_pitch; a.y_pitch = dx_pitch; a.dgb_pitch = dgb_pitch; a.act = act; a.slope = slope; a.eps = eps;
+  const bool half = s2p_env_set("S2P_NORM_CS32") && C % 32 == 0;
+  dim3 grid(N, cdiv(C, half ? 32 : 64));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == S2P_F32) { if (half) hipLaunchKernelGGL((in_fused_bwd_kernel<float, 32>), grid, dim3(1024), 0, st, a);
+                          else hipLaunchKernelGGL((in_fused_bwd_kernel<float, 64>), grid, dim3(1024), 0, st, a); }
+  else { if (half) hipLaunchKernelGGL((in_fused_bwd_kernel<__bf16, 32>), grid, dim3(1024), 0, st, a);
+         else hipLaunchKernelGGL((in_fused_bwd_kernel<__bf16, 64>), grid, dim3(1024), 0, st, a); }
+  S2P_CHECK_LAUNCH("in_fused_bwd_kernel");
+  return 0;
 }
 
 extern "C" int s2p_channel_sum(int dtype, const void* dy, int64_t pixels, int C, int pitch, float* db,

@@ -232,16 +232,15 @@ def in_bwd(da, x, C, stats, gb=None, gb_off=0, gb_st=None, st_off=0, act=ACT_NON
     el = N * H * W * C * x.element_size()
     # reduce reads x, da (+gamma, beta); apply reads the same and writes dx (+dgamma, dbeta)
     pr = _ProfNorm("norm_bwd", x, C, el * ((4 + 4 + 3) if gb is not None else (2 + 2 + 1)), gb is not None)
-    check(lib().s2p_in_bwd_reduce(dt, ptr(da), da.shape[3], ptr(x), N, H * W, C, xp, ptr(stats), gbp, gb_pitch, stp,
-                                  st_pitch, act, slope, IN_EPS, ptr(sums), stream()), "s2p_in_bwd_reduce")
     dx = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
     dgbp = dgb.data_ptr() + dgb_off * dgb.element_size() if dgb is not None else None
     dstp = dgb_st.data_ptr() + dst_off * 4 if dgb_st is not None else None
     _ = ptr(dgb), ptr(dgb_st)
-    check(lib().s2p_in_bwd_apply(dt, ptr(da), da.shape[3], ptr(x), N, H * W, C, xp, ptr(stats), gbp, gb_pitch, stp,
-                                 st_pitch, act, slope, IN_EPS, ptr(sums), ptr(dx), C, dgbp,
-                                 dgb.shape[3] if dgb is not None else 0, dstp,
-                                 dgb_st.shape[1] if dgb_st is not None else 0, stream()), "s2p_in_bwd_apply")
+    # one fused launch for small planes, the reduce + apply pair otherwise (s2p_in_norm_bwd decides)
+    check(lib().s2p_in_norm_bwd(dt, ptr(da), da.shape[3], ptr(x), N, H * W, C, xp, ptr(stats), gbp, gb_pitch, stp,
+                                st_pitch, act, slope, IN_EPS, ptr(sums), ptr(dx), C, dgbp,
+                                dgb.shape[3] if dgb is not None else 0, dstp,
+                                dgb_st.shape[1] if dgb_st is not None else 0, stream()), "s2p_in_norm_bwd")
     pr.done()
     return dx
 
