@@ -11,6 +11,16 @@ from .. import ops
 from .._lib import chunk_elems
 
 
+OVERLAP_VGG = True      # VGG branch of the G loss on a side stream (tools/ab_step.py flips it for an A/B)
+
+
+def _vgg_stream(model):
+    s = getattr(model, "_vgg_side", None)
+    if s is None:
+        s = model._vgg_side = torch.cuda.Stream()
+    return s
+
+
 def _anchor(net):
     a = getattr(net, "_anchor", None)
     if a is None or a.device != net.store.master.device:
@@ -95,6 +105,32 @@ class _GLossNode(torch.autograd.Function):
         N, H, W, ce = fake.shape
         dt = fake.dtype
         losses = torch.zeros(4, dtype=torch.float32, device=fake.device)
+        # pixel L1 + VGG share the NHWC copy of the real image
+        both = torch.empty((2 * N, H, W, ce), dtype=dt, device=fake.device)
+        both[:N].copy_(fake)
+        ops.nchw_to_nhwc(real_image, dt, ce, out=both[N:])
+        d_fake = torch.zeros_like(fake)
+        if opt.lambda_l1 > 0:
+            ops.l1_loss(both[:N], both[N:], opt.lambda_l1 / (N * 3 * H * W), losses[3:4], d_fake)
+        # The perceptual (VGG) branch and the discriminator branch are independent given `fake`: VGG runs on a side stream,
+        # concurrently with D (the fork / join is captured by hipGraph); two MFMA-bound chains of mid-sized launches fill each
+        # other's tails and inter-kernel gaps.
+        main = torch.cuda.current_stream()
+        vgg_on_side = (not opt.no_vgg_loss) and OVERLAP_VGG
+        vs = _vgg_stream(model) if vgg_on_side else main
+        vctx, tap_grads = None, None
+        if not opt.no_vgg_loss:
+            from .networks.loss import VGG_WEIGHTS
+            if vgg_on_side:
+                vs.wait_stream(main)
+                both.record_stream(vs); losses.record_stream(vs)
+            with torch.cuda.stream(vs):
+                taps, vctx = model.vgg.fwd_nhwc(both)
+                tap_grads = []
+                for wk, t in zip(VGG_WEIGHTS, taps):
+                    tg = torch.empty_like(t[:N])
+                    ops.l1_loss(t[:N], t[N:], opt.lambda_vgg * wk / t[:N].numel(), losses[2:3], tg)
+                    tap_grads.append(tg)
         x = _build_d_input(model, fake, prev_image, real_image)
         if model.before_netD is not None:       # data-parallel hook: D's weights of the previous step must have landed
             model.before_netD()
@@ -112,22 +148,9 @@ class _GLossNode(torch.autograd.Function):
                     ops.l1_loss(f[:N], f[N:], opt.lambda_feat / num_D / half, losses[1:2], gf)
                     g[j] = gf
             grads.append(g)
-        # pixel L1 + VGG share the NHWC copy of the real image
-        both = torch.empty((2 * N, H, W, ce), dtype=dt, device=fake.device)
-        both[:N].copy_(fake)
-        ops.nchw_to_nhwc(real_image, dt, ce, out=both[N:])
-        d_fake = torch.zeros_like(fake)
-        if opt.lambda_l1 > 0:
-            ops.l1_loss(both[:N], both[N:], opt.lambda_l1 / (N * 3 * H * W), losses[3:4], d_fake)
-        vctx, tap_grads = None, None
-        if not opt.no_vgg_loss:
-            from .networks.loss import VGG_WEIGHTS
-            taps, vctx = model.vgg.fwd_nhwc(both)
-            tap_grads = []
-            for wk, t in zip(VGG_WEIGHTS, taps):
-                tg = torch.empty_like(t[:N])
-                ops.l1_loss(t[:N], t[N:], opt.lambda_vgg * wk / t[:N].numel(), losses[2:3], tg)
-                tap_grads.append(tg)
+        if vgg_on_side:
+            main.wait_stream(vs)
+        ctx.vgg_on_side = vgg_on_side
         ctx.model, ctx.dctx, ctx.grads, ctx.vctx, ctx.tap_grads, ctx.d_fake, ctx.N = \
             model, dctx, grads, vctx, tap_grads, d_fake, N
         # one zero-dim output per loss term (not one [4] tensor indexed by the caller): the trainer's
@@ -150,10 +173,21 @@ class _GLossNode(torch.autograd.Function):
                     ops.scale_(t, g[2:3])
             ops.scale_(ctx.d_fake, g[3:4])
         d_fake = ctx.d_fake
+        main = torch.cuda.current_stream()
+        dv = None
+        if ctx.vctx is not None:                # VGG backward on its side stream, under the discriminator backward
+            vs = _vgg_stream(model) if ctx.vgg_on_side else main
+            if ctx.vgg_on_side:
+                vs.wait_stream(main)
+            with torch.cuda.stream(vs):
+                dv = model.vgg.bwd_nhwc(ctx.vctx, ctx.tap_grads, N)
+            if ctx.vgg_on_side:
+                dv.record_stream(main)
         dx = model.netD.bwd_nhwc(ctx.dctx, ctx.grads, need_wgrad=False, need_dx=True, n_keep=N)   # fake half only
         ops.copy_channels(dx, 3, d_fake, 0, 3, accumulate=True, src_rows=N)
-        if ctx.vctx is not None:
-            dv = model.vgg.bwd_nhwc(ctx.vctx, ctx.tap_grads, N)
+        if dv is not None:
+            if ctx.vgg_on_side:
+                main.wait_stream(vs)
             ops.add(d_fake, dv, out=d_fake)
         ctx.dctx = ctx.grads = ctx.vctx = ctx.tap_grads = None
         return d_fake, None, None, None

@@ -1,0 +1,53 @@
+"""Same-box A/B of Python-level switches on the full train step (box-to-box spread on this pool is +-3 %, so variants are
+compared inside ONE process: capture A, time it, capture B, time it, alternating).  Usage:
+    python tools/ab_step.py autograd_nodes.OVERLAP_VGG [rounds]"""
+import os, sys, time, importlib
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+import torch
+from s2p_amd.options.train_options import TrainOptions
+from s2p_amd.trainers.pix2pix_trainer import Pix2PixTrainer
+from s2p_amd.stepgraph import StepGraph
+import io, contextlib
+
+target = sys.argv[1] if len(sys.argv) > 1 else "autograd_nodes.OVERLAP_VGG"
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+modname, attr = target.rsplit(".", 1)
+mod = importlib.import_module("s2p_amd.models." + modname if not modname.startswith("s2p_amd") else modname)
+opt = TrainOptions().parse(["--env_type", "cheetah", "--batchSize", "64", "--precision", "bf16", "--gpu_ids", "0",
+                            "--checkpoints_dir", "/tmp/ab_ck"], quiet=True)
+with contextlib.redirect_stdout(io.StringIO()):
+    tr = Pix2PixTrainer(opt)
+g = torch.Generator().manual_seed(0)
+data = dict(prev_image=(torch.rand(64, 3, 84, 84, generator=g) * 2 - 1).cuda(), image=(torch.rand(64, 3, 84, 84, generator=g) * 2 - 1).cuda(),
+            state=torch.randn(64, 17, generator=g).cuda())
+
+
+def step():
+    tr.run_generator_one_step(data); tr.run_discriminator_one_step(data)
+
+
+def measure(val, n=30):
+    setattr(mod, attr, val)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    sg = StepGraph(); tr.seg = sg
+    sg.capture(step)
+    for _ in range(5):
+        sg.replay()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n):
+        sg.replay()
+    torch.cuda.synchronize()
+    tr.seg = None
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+res = {True: [], False: []}
+for r in range(rounds):
+    for val in (True, False):
+        res[val].append(measure(val))
+        print("round %d  %s=%s  %.3f ms/step" % (r, target, val, res[val][-1]), flush=True)
+for val in (True, False):
+    v = sorted(res[val])
+    print("%s=%s: median %.3f ms  min %.3f ms" % (target, val, v[len(v) // 2], v[0]))
