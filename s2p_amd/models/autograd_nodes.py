@@ -104,6 +104,11 @@ class _GLossNode(torch.autograd.Function):
         opt = model.opt
         N, H, W, ce = fake.shape
         dt = fake.dtype
+        if model.before_netD is not None:
+            # data-parallel hook (a StepGraph cut point): D's weight update of the previous step must have landed before
+            # netD is used below.  It sits here, ahead of the stream fork, because a graph segment cannot end while a
+            # forked side stream has not re-joined.
+            model.before_netD()
         losses = torch.zeros(4, dtype=torch.float32, device=fake.device)
         # pixel L1 + VGG share the NHWC copy of the real image
         both = torch.empty((2 * N, H, W, ce), dtype=dt, device=fake.device)
@@ -132,8 +137,6 @@ class _GLossNode(torch.autograd.Function):
                     ops.l1_loss(t[:N], t[N:], opt.lambda_vgg * wk / t[:N].numel(), losses[2:3], tg)
                     tap_grads.append(tg)
         x = _build_d_input(model, fake, prev_image, real_image)
-        if model.before_netD is not None:       # data-parallel hook: D's weights of the previous step must have landed
-            model.before_netD()
         res, dctx = model.netD.fwd_nhwc(x)
         num_D = len(res)
         grads = []
