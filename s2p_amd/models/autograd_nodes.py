@@ -81,6 +81,41 @@ def _build_d_input(model, fake_nhwc, prev_image, real_image):
     return x
 
 
+def _build_d_half(model, prev_image, image_nchw=None, image_nhwc=None):
+    """One half of the D batch: cat(prev_image, image) on channels (0..2 | 3..5), pitch 8; image given as fp32 NCHW (real)
+    or as the generator's NHWC output (fake)."""
+    dt = model.netD.compute_dtype
+    N, _, H, W = prev_image.shape
+    x = torch.empty((N, H, W, 8), dtype=dt, device=prev_image.device)
+    ops.nchw_to_nhwc(prev_image, dt, 8, out=x, c_off=0, zero_pad=True)
+    if image_nhwc is not None:
+        ops.copy_channels(image_nhwc, 0, x, 3, 3, src_rows=N)
+    else:
+        ops.nchw_to_nhwc(image_nchw, dt, 8, out=x, c_off=3, zero_pad=False)
+    return x
+
+
+def _side(model, name):
+    s = getattr(model, name, None)
+    if s is None:
+        s = torch.cuda.Stream()
+        setattr(model, name, s)
+    return s
+
+
+def vgg_real_prefetch(model, real_image, dt, ce):
+    """G step: the perceptual features of the REAL image depend on nothing the step computes, so they are taken on the VGG
+    side stream while the generator forward runs on the main stream.  Returns the handle _GLossNode consumes."""
+    main = torch.cuda.current_stream()
+    vs = _vgg_stream(model)
+    vs.wait_stream(main)
+    real_image.record_stream(vs)
+    with torch.cuda.stream(vs):
+        real_nhwc = ops.nchw_to_nhwc(real_image, dt, ce)
+        taps, acts = model.vgg.fwd_nhwc(real_nhwc)
+    return dict(real_nhwc=real_nhwc, taps=taps, acts=acts, stream=vs)
+
+
 def _hinge_seed(logits, mode_lo, mode_hi, N, num_D, loss_lo, loss_hi):
     """logits: NHWC [2N,h,w,ce] (1 real channel).  Applies hinge mode_lo to the first N samples and mode_hi to the
     last N (if not None); returns the gradient in the layout of `logits` ([N,...] only when mode_hi is None)."""
@@ -100,41 +135,45 @@ class _GLossNode(torch.autograd.Function):
     """G-step losses: hinge GAN + feature matching (through netD, frozen) + VGG perceptual + pixel L1."""
 
     @staticmethod
-    def forward(ctx, fake, model, prev_image, real_image):
+    def forward(ctx, fake, model, prev_image, real_image, pre):
         opt = model.opt
         N, H, W, ce = fake.shape
         dt = fake.dtype
+        main = torch.cuda.current_stream()
+        if pre is not None:
+            main.wait_stream(pre["stream"])     # VGG(real) prefetch re-joins here (it ran under the generator forward)
         if model.before_netD is not None:
             # data-parallel hook (a StepGraph cut point): D's weight update of the previous step must have landed before
             # netD is used below.  It sits here, ahead of the stream fork, because a graph segment cannot end while a
             # forked side stream has not re-joined.
             model.before_netD()
         losses = torch.zeros(4, dtype=torch.float32, device=fake.device)
-        # pixel L1 + VGG share the NHWC copy of the real image
-        both = torch.empty((2 * N, H, W, ce), dtype=dt, device=fake.device)
-        both[:N].copy_(fake)
-        ops.nchw_to_nhwc(real_image, dt, ce, out=both[N:])
+        real_nhwc = pre["real_nhwc"] if pre is not None else ops.nchw_to_nhwc(real_image, dt, ce)
         d_fake = torch.zeros_like(fake)
         if opt.lambda_l1 > 0:
-            ops.l1_loss(both[:N], both[N:], opt.lambda_l1 / (N * 3 * H * W), losses[3:4], d_fake)
+            ops.l1_loss(fake, real_nhwc, opt.lambda_l1 / (N * 3 * H * W), losses[3:4], d_fake)
         # The perceptual (VGG) branch and the discriminator branch are independent given `fake`: VGG runs on a side stream,
         # concurrently with D (the fork / join is captured by hipGraph); two MFMA-bound chains of mid-sized launches fill each
-        # other's tails and inter-kernel gaps.
-        main = torch.cuda.current_stream()
+        # other's tails and inter-kernel gaps.  VGG sees the fake and the real image as two batches of N: the real one
+        # may already have been done under the generator forward (vgg_real_prefetch).
         vgg_on_side = (not opt.no_vgg_loss) and OVERLAP_VGG
         vs = _vgg_stream(model) if vgg_on_side else main
-        vctx, tap_grads = None, None
+        vctx, tap_grads, vctx_real = None, None, None
         if not opt.no_vgg_loss:
             from .networks.loss import VGG_WEIGHTS
             if vgg_on_side:
                 vs.wait_stream(main)
-                both.record_stream(vs); losses.record_stream(vs)
+                fake.record_stream(vs); losses.record_stream(vs); real_nhwc.record_stream(vs)
             with torch.cuda.stream(vs):
-                taps, vctx = model.vgg.fwd_nhwc(both)
+                if pre is not None:
+                    taps_r, vctx_real = pre["taps"], pre["acts"]
+                else:
+                    taps_r, vctx_real = model.vgg.fwd_nhwc(real_nhwc)
+                taps, vctx = model.vgg.fwd_nhwc(fake)
                 tap_grads = []
-                for wk, t in zip(VGG_WEIGHTS, taps):
-                    tg = torch.empty_like(t[:N])
-                    ops.l1_loss(t[:N], t[N:], opt.lambda_vgg * wk / t[:N].numel(), losses[2:3], tg)
+                for wk, t, tr in zip(VGG_WEIGHTS, taps, taps_r):
+                    tg = torch.empty_like(t)
+                    ops.l1_loss(t, tr, opt.lambda_vgg * wk / t.numel(), losses[2:3], tg)
                     tap_grads.append(tg)
         x = _build_d_input(model, fake, prev_image, real_image)
         res, dctx = model.netD.fwd_nhwc(x)
@@ -156,6 +195,7 @@ class _GLossNode(torch.autograd.Function):
         ctx.vgg_on_side = vgg_on_side
         ctx.model, ctx.dctx, ctx.grads, ctx.vctx, ctx.tap_grads, ctx.d_fake, ctx.N = \
             model, dctx, grads, vctx, tap_grads, d_fake, N
+        ctx.vctx_real, ctx.real_nhwc, ctx.fake = vctx_real, real_nhwc, fake      # (kept for the parity tests' branch masks)
         # one zero-dim output per loss term (not one [4] tensor indexed by the caller): the trainer's
         # sum(losses.values()).mean().backward() then costs no select-backward zero-fill / copy / accumulate kernels
         return tuple(losses.unbind(0))
@@ -192,50 +232,89 @@ class _GLossNode(torch.autograd.Function):
             if ctx.vgg_on_side:
                 main.wait_stream(vs)
             ops.add(d_fake, dv, out=d_fake)
-        ctx.dctx = ctx.grads = ctx.vctx = ctx.tap_grads = None
-        return d_fake, None, None, None
+        ctx.dctx = ctx.grads = ctx.vctx = ctx.tap_grads = ctx.vctx_real = ctx.real_nhwc = ctx.fake = None
+        return d_fake, None, None, None, None
 
 
-def g_losses_apply(model, fake_nhwc, prev_image, real_image):
-    return _GLossNode.apply(fake_nhwc, model, prev_image, real_image)
+def g_losses_apply(model, fake_nhwc, prev_image, real_image, pre=None):
+    return _GLossNode.apply(fake_nhwc, model, prev_image, real_image, pre)
 
 
-class _DLossNode(torch.autograd.Function):
-    """D-step losses: hinge on D(prev, fake.detach()) and D(prev, real); weight grads go to netD's flat buffer."""
+OVERLAP_DREAL = True    # D step: the real half of the discriminator pass on a side stream, under the generator forward
+DREAL_EARLY_BWD = True  # ... including its backward (only when the losses' upstream gradients are known to be 1)
+
+
+class _DStepNode(torch.autograd.Function):
+    """The whole D step as one node: fake = G(prev, state) without gradient, hinge on D(prev, fake) and D(prev, real);
+    weight gradients go to netD's flat buffer.  The two halves of the D batch are independent (InstanceNorm is
+    per-sample), and the real half depends on nothing the step computes: it runs on a side stream while the generator
+    forward occupies the main stream -- forward AND, when the losses' upstream gradients are known to be 1 (the
+    trainer), its backward too.  The fake half follows on the main stream."""
 
     @staticmethod
-    def forward(ctx, anchor, model, fake, prev_image, real_image):
-        N = fake.shape[0]
-        losses = torch.zeros(2, dtype=torch.float32, device=fake.device)
-        x = _build_d_input(model, fake, prev_image, real_image)
-        if model.before_netD is not None:
-            model.before_netD()
-        res, dctx = model.netD.fwd_nhwc(x)
-        num_D = len(res)
-        grads = []
-        for feats in res:
-            g = [None] * len(feats)
-            g[-1] = _hinge_seed(feats[-1], 0, 1, N, num_D, losses[0:1], losses[1:2])
-            grads.append(g)
-        ctx.model, ctx.dctx, ctx.grads, ctx.N = model, dctx, grads, N
+    def forward(ctx, anchor, model, prev_image, state, real_image, fake_given):
+        N = prev_image.shape[0]
+        netD, netG = model.netD, model.netG
+        num_D = netD.num_D
+        dev = prev_image.device
+        losses = torch.zeros(2, dtype=torch.float32, device=dev)
+        main = torch.cuda.current_stream()
+        unit = model.assume_unit_loss_grad
+        use_side = OVERLAP_DREAL and unit
+        side = _side(model, "_dreal_side") if use_side else main
+
+        def half(x, mode, loss_slot, lane):
+            res, dctx = netD.fwd_nhwc(x, lane=lane)
+            grads = []
+            for feats in res:
+                g = [None] * len(feats)
+                g[-1] = _hinge_seed(feats[-1], mode, None, N, num_D, loss_slot, None)
+                grads.append(g)
+            return dctx, grads
+
+        if use_side:
+            side.wait_stream(main)
+            for t in (prev_image, real_image, losses):
+                t.record_stream(side)
+        with torch.cuda.stream(side):
+            xr = _build_d_half(model, prev_image, image_nchw=real_image)
+            # (no nested fork: HIP's stream capture crashed in hipStreamEndCapture with a side stream forked from a side stream)
+            dctx_r, grads_r = half(xr, 1, losses[1:2], None if use_side else 0)
+            if unit and DREAL_EARLY_BWD:               # upstream gradient is 1: the real half's backward can go now
+                netD.bwd_nhwc(dctx_r, grads_r, need_wgrad=True, need_dx=False)
+                dctx_r = grads_r = None
+        if fake_given is None:
+            dt = netG.compute_dtype
+            img = ops.nchw_to_nhwc(prev_image, dt, chunk_elems(dt))
+            fake, _ = netG.fwd_nhwc(img, state, save=False)
+        else:
+            fake = fake_given
+        if use_side:
+            main.wait_stream(side)                     # D.grad is accumulated without atomics: the halves' backwards are ordered
+        xf = _build_d_half(model, prev_image, image_nhwc=fake)
+        dctx_f, grads_f = half(xf, 0, losses[0:1], 0)
+        ctx.model, ctx.N = model, N
+        ctx.dctx_f, ctx.grads_f, ctx.dctx_r, ctx.grads_r = dctx_f, grads_f, dctx_r, grads_r
         return tuple(losses.unbind(0))
 
     @staticmethod
     def backward(ctx, *gs_in):
         model = ctx.model
-        dev = ctx.grads[0][-1].device
+        netD = model.netD
         if not model.assume_unit_loss_grad:
+            dev = ctx.grads_f[0][-1].device
             g = torch.stack([gi.float() if gi is not None else torch.zeros((), device=dev) for gi in gs_in])
-            for gs in ctx.grads:
-                t = gs[-1]
-                half = t.numel() // 2
-                flat = t.view(-1)
-                ops.scale_(flat[:half], g[0:1])
-                ops.scale_(flat[half:], g[1:2])
-        model.netD.bwd_nhwc(ctx.dctx, ctx.grads, need_wgrad=True, need_dx=False)
-        ctx.dctx = ctx.grads = None
-        return None, None, None, None, None
+            for gs in ctx.grads_f:
+                ops.scale_(gs[-1], g[0:1])
+            for gs in ctx.grads_r:
+                ops.scale_(gs[-1], g[1:2])
+        if ctx.dctx_r is not None:
+            netD.bwd_nhwc(ctx.dctx_r, ctx.grads_r, need_wgrad=True, need_dx=False)
+        netD.bwd_nhwc(ctx.dctx_f, ctx.grads_f, need_wgrad=True, need_dx=False)
+        ctx.dctx_f = ctx.grads_f = ctx.dctx_r = ctx.grads_r = None
+        return None, None, None, None, None, None
 
 
-def d_losses_apply(model, fake_nhwc, prev_image, real_image):
-    return _DLossNode.apply(_anchor(model.netD), model, fake_nhwc.detach(), prev_image, real_image)
+def d_step_apply(model, prev_image, state, real_image, fake_nhwc=None):
+    return _DStepNode.apply(_anchor(model.netD), model, prev_image, state, real_image,
+                            fake_nhwc.detach() if fake_nhwc is not None else None)

@@ -137,36 +137,40 @@ class MultiscaleDiscriminator(BaseNetwork):
             d.compute_dtype = dt
             d.finalized = True
 
-    def _side_stream(self):
-        if os.environ.get("S2P_NO_SIDE_STREAM"):          # A/B switch: everything on the current stream
-            return torch.cuda.current_stream()
-        s = getattr(self, "_side", None)
-        if s is None:
-            s = self._side = torch.cuda.Stream()
-        return s
+    def _side_stream(self, lane=0):
+        """Side stream for the coarser scales, one per `lane`: two concurrent passes (the D step runs the real half of its
+        batch on its own stream, lane 1) must not serialise through a shared side stream."""
+        d = self.__dict__.setdefault("_sides", {})
+        if lane not in d:
+            d[lane] = torch.cuda.Stream()
+        return d[lane]
 
-    def fwd_nhwc(self, x):
+    def fwd_nhwc(self, x, lane=0):
         """The scales are independent given their inputs; the coarser scales' kernels are too small to fill 256 CUs, so
         scales >= 1 run on a side stream, overlapped with scale 0 (fork/join captured by hipGraph)."""
         self._require_ready()
         main = torch.cuda.current_stream()
-        side = self._side_stream()
+        side = self._side_stream(lane) if lane is not None else main      # lane None: every scale on the calling stream
         subs = self.subnets()
         xs = [x]
         for i in range(1, self.num_D):
             xs.append(ops.avgpool_fwd(xs[-1]))
         result, ctx = [None] * self.num_D, [None] * self.num_D
-        side.wait_stream(main)
+        if side is not main:
+            side.wait_stream(main)
         with torch.cuda.stream(side):
             for i in range(1, self.num_D):
-                xs[i].record_stream(side)
+                if side is not main:
+                    xs[i].record_stream(side)
                 feats, saved = subs[i].fwd_nhwc(xs[i])
-                for f in feats:
-                    f.record_stream(main)
+                if side is not main:
+                    for f in feats:
+                        f.record_stream(main)
                 result[i], ctx[i] = feats, (xs[i], saved)
         feats, saved = subs[0].fwd_nhwc(xs[0])
         result[0], ctx[0] = feats, (xs[0], saved)
-        main.wait_stream(side)
+        if side is not main:
+            main.wait_stream(side)
         return result, ctx
 
     def bwd_nhwc(self, ctx, grads, need_wgrad=True, need_dx=True, n_keep=None):

@@ -251,8 +251,6 @@ class S2PGenerator(BaseNetwork):
         return out, ctx
 
     def _side_stream(self):
-        if os.environ.get("S2P_NO_SIDE_STREAM"):          # A/B switch: everything on the current stream
-            return torch.cuda.current_stream()
         s = getattr(self, "_side", None)
         if s is None:
             s = self._side = torch.cuda.Stream()

@@ -10,7 +10,8 @@ import torch
 import torch.nn as nn
 
 from . import networks
-from .autograd_nodes import d_losses_apply, g_losses_apply, generator_apply, nhwc_to_nchw_apply
+from . import autograd_nodes
+from .autograd_nodes import d_step_apply, g_losses_apply, generator_apply, nhwc_to_nchw_apply, vgg_real_prefetch
 from .networks.loss import VGG19
 
 
@@ -144,8 +145,13 @@ class Pix2PixModel(nn.Module):
         raise ValueError("|mode| is invalid")
 
     def compute_generator_loss(self, prev, state, real):
+        pre = None
+        if not self.opt.no_vgg_loss and autograd_nodes.OVERLAP_VGG:
+            # VGG features of the real image: on the VGG side stream, under the generator forward below
+            from .._lib import chunk_elems
+            pre = vgg_real_prefetch(self, real, self.compute_dtype, chunk_elems(self.compute_dtype))
         fake = generator_apply(self.netG, prev, state)                 # NHWC compute dtype, autograd node
-        L = g_losses_apply(self, fake, prev, real)
+        L = g_losses_apply(self, fake, prev, real, pre)
         G_losses = {"GAN": L[0]}
         if not self.opt.no_ganFeat_loss:
             G_losses["GAN_Feat"] = L[1]
@@ -157,12 +163,8 @@ class Pix2PixModel(nn.Module):
         return G_losses, fake
 
     def compute_discriminator_loss(self, prev, state, real, reuse_fake=False):
-        if reuse_fake and getattr(self, "_last_fake", None) is not None:
-            fake = self._last_fake
-        else:
-            with torch.no_grad():
-                fake = generator_apply(self.netG, prev, state)
-        L = d_losses_apply(self, fake, prev, real)
+        fake = self._last_fake if (reuse_fake and getattr(self, "_last_fake", None) is not None) else None
+        L = d_step_apply(self, prev, state, real, fake)     # generator forward (no grad) + both D halves, one node
         return {"D_Fake": L[0], "D_real": L[1]}
 
     def generated_to_nchw(self, fake_nhwc):

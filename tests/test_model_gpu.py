@@ -96,7 +96,7 @@ def build(precision, tmp_path, extra=(), env="cheetah"):
 
 # ---- branches the HIP forward took, read from the activations its autograd nodes saved -------------------------------
 def _nchw(t, C):
-    return t[..., :C].float().cpu().permute(0, 3, 1, 2).contiguous()
+    return t.detach()[..., :C].float().cpu().permute(0, 3, 1, 2).contiguous()
 
 
 def generator_masks(net, c):
@@ -132,26 +132,39 @@ def discriminator_masks(netD, dctx, N, with_feat_l1):
     return m
 
 
-def vgg_masks(acts, N):
+def vgg_masks(lnode, N):
+    """lnode: _GLossNode's backward object.  The product runs VGG on the fake and on the real image as two batches of N
+    (the real one under the generator forward); the oracle runs cat([fake; real]): masks are concatenated on the batch."""
     from s2p_amd.models.networks.loss import VGG_TAPS
     m = {}
     npool, ntap = 0, 0
-    for kind, name, hin, o in acts:
+    for (kind, name, hin_f, o_f), (_, _, hin_r, o_r) in zip(lnode.vctx, lnode.vctx_real):
         if kind == "P":
-            x = _nchw(hin, hin.shape[3])
+            x = torch.cat([_nchw(hin_f, hin_f.shape[3]), _nchw(hin_r, hin_r.shape[3])], 0)
             B, C, H, W = x.shape
             Ho, Wo = H // 2, W // 2
             win = x[:, :, :Ho * 2, :Wo * 2].reshape(B, C, Ho, 2, Wo, 2).permute(0, 1, 2, 4, 3, 5).reshape(B, C, Ho, Wo, 4)
             m[f"vgg.pool{npool}"] = win.argmax(4)          # first maximum, as s2p_maxpool2x2_bwd routes it
             npool += 1
         else:
-            f = _nchw(o, o.shape[3])
-            m[f"vgg.{name}"] = f > 0
+            ff, fr = _nchw(o_f, o_f.shape[3]), _nchw(o_r, o_r.shape[3])
+            m[f"vgg.{name}"] = torch.cat([ff, fr], 0) > 0
             if name in VGG_TAPS:
-                m[f"l1.vgg{ntap}"] = torch.sign(f[:N] - f[N:])
+                m[f"l1.vgg{ntap}"] = torch.sign(ff - fr)
                 ntap += 1
-    both = _nchw(acts[0][2], 3)
-    m["l1.pix"] = torch.sign(both[:N] - both[N:])
+    m["l1.pix"] = torch.sign(_nchw(lnode.fake, 3) - _nchw(lnode.real_nhwc, 3))
+    return m
+
+
+def dstep_masks(netD, dnode, N):
+    """_DStepNode keeps one ctx per half of the D batch (fake, real): concatenate to the oracle's cat([fake; real])."""
+    m = {}
+    for k, (d, (_, sf), (_, sr)) in enumerate(zip(netD.subnets(), dnode.dctx_f, dnode.dctx_r)):
+        nl = d.n_layers
+        for n in range(nl):
+            m[f"D{k}.model{n}"] = torch.cat([_nchw(sf[n][3], d.chans[n]), _nchw(sr[n][3], d.chans[n])], 0) > 0
+        m[f"hinge.fake{k}"] = (1.0 + _nchw(sf[nl][3], 1)) > 0
+        m[f"hinge.real{k}"] = (1.0 - _nchw(sr[nl][3], 1)) > 0
     return m
 
 
@@ -268,7 +281,7 @@ def test_train_step_losses_and_grads(hip_device, tmp_path, precision, ltol, gtol
     lnode, gnode = g_losses["GAN"].grad_fn, fake.grad_fn
     masks = generator_masks(model.netG, gnode.c)
     masks.update(discriminator_masks(model.netD, lnode.dctx, N, with_feat_l1=True))
-    masks.update(vgg_masks(lnode.vctx, N))
+    masks.update(vgg_masks(lnode, N))
     sum(g_losses.values()).mean().backward()
     torch.cuda.synchronize()
     pg64 = to64(pg)
@@ -283,8 +296,8 @@ def test_train_step_losses_and_grads(hip_device, tmp_path, precision, ltol, gtol
     model.netD.store.zero_grad()
     d_losses = model(data, mode="discriminator")
     dnode = d_losses["D_Fake"].grad_fn
-    dmasks = discriminator_masks(model.netD, dnode.dctx, N, with_feat_l1=False)
-    fake_hip = _nchw(dnode.dctx[0][0][:N], 6)[:, 3:6].double()
+    dmasks = dstep_masks(model.netD, dnode, N)
+    fake_hip = _nchw(dnode.dctx_f[0][0], 6)[:, 3:6].double()
     sum(d_losses.values()).mean().backward()
     torch.cuda.synchronize()
     pd64 = to64(pd)
@@ -311,7 +324,7 @@ def test_loss_weights_reach_the_gradients(hip_device, tmp_path):
     lnode, gnode = g_losses["GAN"].grad_fn, fake.grad_fn
     masks = generator_masks(model.netG, gnode.c)
     masks.update(discriminator_masks(model.netD, lnode.dctx, 2, with_feat_l1=True))
-    masks.update(vgg_masks(lnode.vctx, 2))
+    masks.update(vgg_masks(lnode, 2))
     sum(wts[k] * v for k, v in g_losses.items()).backward()
     torch.cuda.synchronize()
     pg64 = to64(pg)
@@ -322,8 +335,8 @@ def test_loss_weights_reach_the_gradients(hip_device, tmp_path):
     model.netD.store.zero_grad()
     d_losses = model(data, mode="discriminator")
     dnode = d_losses["D_Fake"].grad_fn
-    dmasks = discriminator_masks(model.netD, dnode.dctx, 2, with_feat_l1=False)
-    fake_hip = _nchw(dnode.dctx[0][0][:2], 6)[:, 3:6].double()
+    dmasks = dstep_masks(model.netD, dnode, 2)
+    fake_hip = _nchw(dnode.dctx_f[0][0], 6)[:, 3:6].double()
     (3.0 * d_losses["D_Fake"] + 0.25 * d_losses["D_real"]).backward()
     torch.cuda.synchronize()
     pd64 = to64(pd)
@@ -401,6 +414,30 @@ def test_trainer_step_matches_oracle_adam(hip_device, tmp_path):
         total += int(big.sum())
     print(f"Adam step: {bad} of {total} well-conditioned weights differ from the oracle update by more than 2 % of lr")
     assert total > 1e5 and bad <= 1e-5 * total
+    # ---- the trainer's D step (unit upstream gradients: the real half of the D batch runs forward AND backward on a side
+    # stream under the generator forward, the fake half follows): updated D weights against the oracle's D step taken with
+    # the generator weights the HIP G step just produced
+    tr.run_discriminator_one_step(dict(prev_image=prev, state=state, image=real))
+    tr.sync(); torch.cuda.synchronize()
+    newD = {k: v.detach().cpu().double() for k, v in model.netD.named_parameters()}
+    pd64 = to64(pd)
+    D64 = O.discriminator_losses(new, pd64, prev.double(), state.double(), real.double(), spec)
+    sum(D64.values()).backward()
+    for k in D64:
+        assert abs(float(tr.d_losses[k]) - float(D64[k])) <= 1e-4 * max(abs(float(D64[k])), 1e-2), k
+    lrD = opt.lr * 2 if not opt.no_TTUR else opt.lr
+    bad = total = 0
+    gmax = max(float(v.grad.abs().max()) for v in pd64.values())
+    for k, p0 in pd.items():
+        g = pd64[k].grad
+        if float(g.abs().max()) < 1e-9 * gmax:
+            continue
+        p1, _, _ = O.adam_step(p0.double(), g, torch.zeros_like(g), torch.zeros_like(g), 1, lrD, b1, b2)
+        big = g.abs() > 0.05 * g.abs().max()
+        bad += int((((newD[k] - p0.double()) - (p1 - p0.double())).abs() > 0.02 * lrD)[big].sum())
+        total += int(big.sum())
+    print(f"Adam step (D): {bad} of {total} well-conditioned weights differ from the oracle update by more than 2 % of lr")
+    assert total > 1e4 and bad <= 1e-5 * total
 
 
 def test_rollout_matches_oracle_and_golden(hip_device, tmp_path):
