@@ -21,6 +21,8 @@ from .base_network import BaseNetwork
 from .layers import ConvLayer
 
 LRELU = 0.2
+WGRAD_SIDE = False       # experiment (tools/ab_step.py): batched weight gradients on a side stream
+COND_SIDE = False        # experiment: image-conditioning branch on its own stream, concurrent with the encoder (measured neutral)
 
 
 class _Linear(nn.Module):
@@ -207,11 +209,20 @@ class S2PGenerator(BaseNetwork):
             st_all = ops.linear_fwd(h, pk.w_fwd, pk.bias, pk.Cpad, pk.R)  # [N, 12*2C] fp32
         st_all.record_stream(main)          # allocated on the side stream, consumed by the norms on the main stream
         state.record_stream(side)
-        # image conditioning
+        # image conditioning (shared conv + the 12 gamma/beta heads as one grouped conv): independent of the encoder below, so
+        # it runs on its own side stream, concurrently with it (both forked from the main stream: no nested forks)
         hq, wq = H >> self.n_down, W >> self.n_down
-        seg = ops.resize_nearest(img, hq, wq)
-        actv = L["shared"].fwd(seg, act=ACT_RELU)                       # [N,h,w,12*nh]
-        gb_all = L["gb"].fwd(actv)                                      # [N,h,w,12*2C]
+        cs = self._cond_stream() if COND_SIDE else main
+        if cs is not main:
+            cs.wait_stream(main)
+            img.record_stream(cs)
+        with torch.cuda.stream(cs):
+            seg = ops.resize_nearest(img, hq, wq)
+            actv = L["shared"].fwd(seg, act=ACT_RELU)                   # [N,h,w,12*nh]
+            gb_all = L["gb"].fwd(actv)                                  # [N,h,w,12*2C]
+        if cs is not main:
+            for t in (seg, actv, gb_all):
+                t.record_stream(main)
         # encoder
         enc = []
         x = L["stem"].fwd(img)
@@ -226,6 +237,8 @@ class S2PGenerator(BaseNetwork):
             enc.append((xin, x, s, a))
         # MAT residual blocks
         main.wait_stream(side)                                          # st_all is needed from here on
+        if cs is not main:
+            main.wait_stream(cs)                                        # ... and the gamma/beta maps
         blocks = []
         x = a
         for b in range(self.n_blocks):
@@ -249,6 +262,18 @@ class S2PGenerator(BaseNetwork):
             ctx.update(hs=hs, st_all=st_all, seg=seg, actv=actv, gb_all=gb_all, enc=enc, blocks=blocks, dec=dec,
                        out=out, last=x)
         return out, ctx
+
+    def _cond_stream(self):
+        s = getattr(self, "_cside", None)
+        if s is None:
+            s = self._cside = torch.cuda.Stream()
+        return s
+
+    def _wgrad_stream(self):
+        s = getattr(self, "_wside", None)
+        if s is None:
+            s = self._wside = torch.cuda.Stream()
+        return s
 
     def _side_stream(self):
         s = getattr(self, "_side", None)
@@ -292,18 +317,33 @@ class S2PGenerator(BaseNetwork):
             d_nA = L[f"b{b}c0"].dgrad(d_c0, nA.shape)
             d_xb = ops.in_bwd(d_nA, x, C, sA, gb_all, o0, st_all, o0, ACT_LRELU, LRELU, dgb_all, o0, dst_all, o0)
             dx = ops.add(dx, d_xb, out=d_xb)
-        ConvLayer.wgrad_many(wjobs)
-        # image-conditioning branch (batched)
         actv, seg = ctx["actv"], ctx["seg"]
-        L["gb"].wgrad(actv, dgb_all)
-        # every gradient of the flat buffer's tail [early_grad_offset, end) is final now (data-parallel hook: the trainer
-        # starts that bucket's all-reduce here, under the rest of this backward)
-        if self.on_early_grads is not None:
-            self.on_early_grads()
-        d_actv = L["gb"].dgrad(dgb_all, actv.shape, aux=actv, epi=EPI_MUL_ACTGRAD, aux_act=ACT_RELU)
-        L["shared"].wgrad(seg, d_actv)
-        # state path backward on the side stream, overlapped with the encoder backward below
         main = torch.cuda.current_stream()
+        if WGRAD_SIDE and self.on_early_grads is None:
+            # (single rank) the two big batched weight-gradient launches overlap the rest of the backward on a side stream
+            ws = self._wgrad_stream()
+            ws.wait_stream(main)
+            with torch.cuda.stream(ws):
+                ConvLayer.wgrad_many(wjobs)
+                L["gb"].wgrad(actv, dgb_all)
+        else:
+            ws = None
+            ConvLayer.wgrad_many(wjobs)
+            # image-conditioning branch (batched)
+            L["gb"].wgrad(actv, dgb_all)
+            # every gradient of the flat buffer's tail [early_grad_offset, end) is final now (data-parallel hook: the trainer
+            # starts that bucket's all-reduce here, under the rest of this backward)
+            if self.on_early_grads is not None:
+                self.on_early_grads()
+        # backward of the image-conditioning branch on its side stream, concurrent with the encoder backward below
+        cs = self._cond_stream() if COND_SIDE else main
+        if cs is not main:
+            cs.wait_stream(main)
+            dgb_all.record_stream(cs)
+        with torch.cuda.stream(cs):
+            d_actv = L["gb"].dgrad(dgb_all, actv.shape, aux=actv, epi=EPI_MUL_ACTGRAD, aux_act=ACT_RELU)
+            L["shared"].wgrad(seg, d_actv)
+        # state path backward on the side stream, overlapped with the encoder backward below
         side = self._side_stream()
         side.wait_stream(main)
         dst_all.record_stream(side)
@@ -325,6 +365,10 @@ class S2PGenerator(BaseNetwork):
         dxe = ops.in_bwd(dx, x, self.ngf, s, act=ACT_RELU)
         L["stem"].wgrad(img, dxe)
         main.wait_stream(side)
+        if cs is not main:
+            main.wait_stream(cs)
+        if ws is not None:
+            main.wait_stream(ws)
 
     # ---- public torch-style API --------------------------------------------------------------------------------
     def forward(self, prev_image, state):

@@ -12,7 +12,7 @@ import io, contextlib
 target = sys.argv[1] if len(sys.argv) > 1 else "autograd_nodes.OVERLAP_VGG"
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 modname, attr = target.rsplit(".", 1)
-mod = importlib.import_module("s2p_amd.models." + modname if not modname.startswith("s2p_amd") else modname)
+mod = importlib.import_module(modname if modname.startswith("s2p_amd") else "s2p_amd.models." + modname)
 opt = TrainOptions().parse(["--env_type", "cheetah", "--batchSize", "64", "--precision", "bf16", "--gpu_ids", "0",
                             "--checkpoints_dir", "/tmp/ab_ck"], quiet=True)
 with contextlib.redirect_stdout(io.StringIO()):
