@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", type=str, default="", help="torch.distributed backend (default nccl = RCCL; gloo for a 1-GPU rehearsal)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use GPU 0")
+    ap.add_argument("--serial-streams", action="store_true",
+                    help="run every launch on one stream (no overlap of independent chains): the configuration in which a "
+                         "kernel's own duration is measured (rocprofv3 evidence for the roofline numbers); slower end to end")
     return ap.parse_args()
 
 
@@ -154,6 +157,7 @@ def main():
         dist.init_process_group(backend=args.backend)
 
     from s2p_amd import ops
+    ops.SERIALIZE = bool(args.serial_streams)
     from s2p_amd.options.train_options import TrainOptions
     from s2p_amd.trainers.pix2pix_trainer import Pix2PixTrainer
 
@@ -225,8 +229,10 @@ def main():
     if not args.no_roofline:
         # every rank runs the instrumented step (it contains the gradient all-reduces); rank 0 reports
         ops.PROFILE = []
+        ops.SERIALIZE = True        # one serial chain of launches: a launch's event pair times that kernel alone
         eager_step()
         trainer.sync(); torch.cuda.synchronize()
+        ops.SERIALIZE = bool(args.serial_streams)
         all_recs, ops.PROFILE = ops.PROFILE, None
     if not args.no_roofline and rank == 0:
         recs = [r for r in all_recs if r["kind"] in ("fwd", "dgrad", "wgrad")]
@@ -273,7 +279,9 @@ def main():
                         break
         except Exception as e:      # evidence file unreadable: report null rather than fail the bench
             print("[bench] traffic: %s" % e, file=sys.stderr)
-        roofline = dict(bound="mfma", kernel="implicit-GEMM conv family: conv_halo/conv_dma/conv_gather (fwd, dgrad) + wgrad_dma/wgrad "
+        roofline = dict(bound="mfma", measured="one instrumented eager step with every launch on ONE stream (HIP events around each "
+                                               "launch): kernel-alone durations; rocprofv3 counterpart: bench.py --serial-streams",
+                        kernel="implicit-GEMM conv family: conv_halo/conv_dma/conv_gather (fwd, dgrad) + wgrad_dma/wgrad "
                                              "+ thin_tiled kernels, all %d launches of one step" % len(recs),
                         dominant_layer=dominant, spade_resblk_fwd_bwd=resblk,
                         achieved=round(ach, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
@@ -298,6 +306,7 @@ def main():
                                    "+ L1, Adam x2), %dx%d %s, netG=s2p, netD=multiscale(2)" % (args.size, args.size, args.env_type),
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch,
                        "parallelism": "dp%d" % world, "hip_graph": bool(use_graph), "graph_segments": sg.n_graphs,
+                       "streams": "serial" if args.serial_streams else "overlapped",
                        "vgg_weights": "seeded stand-in (ImageNet weights unobtainable offline)"},
             "roofline": roofline, "cpu_baseline": cpu, "losses": {k: round(v, 4) for k, v in losses.items()},
         }

@@ -156,7 +156,7 @@ class _GLossNode(torch.autograd.Function):
         # concurrently with D (the fork / join is captured by hipGraph); two MFMA-bound chains of mid-sized launches fill each
         # other's tails and inter-kernel gaps.  VGG sees the fake and the real image as two batches of N: the real one
         # may already have been done under the generator forward (vgg_real_prefetch).
-        vgg_on_side = (not opt.no_vgg_loss) and OVERLAP_VGG
+        vgg_on_side = (not opt.no_vgg_loss) and OVERLAP_VGG and not ops.SERIALIZE
         vs = _vgg_stream(model) if vgg_on_side else main
         vctx, tap_grads, vctx_real = None, None, None
         if not opt.no_vgg_loss:
@@ -260,7 +260,7 @@ class _DStepNode(torch.autograd.Function):
         losses = torch.zeros(2, dtype=torch.float32, device=dev)
         main = torch.cuda.current_stream()
         unit = model.assume_unit_loss_grad
-        use_side = OVERLAP_DREAL and unit
+        use_side = OVERLAP_DREAL and unit and not ops.SERIALIZE
         side = _side(model, "_dreal_side") if use_side else main
 
         def half(x, mode, loss_slot, lane):

@@ -150,7 +150,7 @@ class MultiscaleDiscriminator(BaseNetwork):
         scales >= 1 run on a side stream, overlapped with scale 0 (fork/join captured by hipGraph)."""
         self._require_ready()
         main = torch.cuda.current_stream()
-        side = self._side_stream(lane) if lane is not None else main      # lane None: every scale on the calling stream
+        side = self._side_stream(lane) if (lane is not None and not ops.SERIALIZE) else main   # lane None: one stream
         subs = self.subnets()
         xs = [x]
         for i in range(1, self.num_D):

@@ -276,6 +276,8 @@ class S2PGenerator(BaseNetwork):
         return s
 
     def _side_stream(self):
+        if ops.SERIALIZE:
+            return torch.cuda.current_stream()
         s = getattr(self, "_side", None)
         if s is None:
             s = self._side = torch.cuda.Stream()

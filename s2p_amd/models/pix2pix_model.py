@@ -11,6 +11,7 @@ import torch.nn as nn
 
 from . import networks
 from . import autograd_nodes
+from .. import ops as ops_mod
 from .autograd_nodes import d_step_apply, g_losses_apply, generator_apply, nhwc_to_nchw_apply, vgg_real_prefetch
 from .networks.loss import VGG19
 
@@ -146,7 +147,7 @@ class Pix2PixModel(nn.Module):
 
     def compute_generator_loss(self, prev, state, real):
         pre = None
-        if not self.opt.no_vgg_loss and autograd_nodes.OVERLAP_VGG:
+        if not self.opt.no_vgg_loss and autograd_nodes.OVERLAP_VGG and not ops_mod.SERIALIZE:
             # VGG features of the real image: on the VGG side stream, under the generator forward below
             from .._lib import chunk_elems
             pre = vgg_real_prefetch(self, real, self.compute_dtype, chunk_elems(self.compute_dtype))

@@ -14,6 +14,13 @@ from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, EPI_ADD, EPI_MUL_ACT
 
 IN_EPS = 1e-5
 
+# When True, every "side stream" helper of the networks returns the CURRENT stream: the step runs as one serial chain of
+# launches.  bench.py sets it for its instrumented roofline step only, so that a kernel's HIP-event duration is that of the
+# kernel alone (in the product configuration independent chains overlap on several streams and would inflate each
+# other's per-launch times).
+SERIALIZE = False
+
+
 # Optional in-situ profiler used by bench.py's roofline leg: when PROFILE is a list, every MFMA conv launch is
 # bracketed by two events on the launch stream and logged with its algorithmic FLOPs (2*MACs, un-padded channels).
 PROFILE = None

@@ -11,11 +11,16 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG 
   > $R/gpurun_out/prof_${TAG}_bench_under_rocprof.json 2> $R/gpurun_out/prof_${TAG}.err
 python3 $R/tools/kernel_summary.py $R/gpurun_out/prof_$TAG $R/gpurun_out/prof_${TAG}_kernel_summary.csv 63
 cp $(ls $R/gpurun_out/prof_$TAG/*/*kernel_stats.csv | head -1) $R/gpurun_out/prof_${TAG}_kernel_stats.csv 2>/dev/null
+# same command with every launch on one stream: per-kernel durations without contention from overlapping chains (what
+# bench.py's roofline leg measures live)
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_serial -- python3 $R/bench.py --no-cpu-baseline \
+  --serial-streams > $R/gpurun_out/prof_${TAG}_serial_bench_under_rocprof.json 2> $R/gpurun_out/prof_${TAG}_serial.err
+python3 $R/tools/kernel_summary.py $R/gpurun_out/prof_${TAG}_serial $R/gpurun_out/prof_${TAG}_serial_kernel_summary.csv 63
 i=0
 for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${TAG}_$i -- python3 $R/bench.py --steps 2 --warmup 1 \
-    --no-graph --no-cpu-baseline --no-roofline > /dev/null 2> $R/gpurun_out/pmc_${TAG}_$i.err
+    --no-graph --no-cpu-baseline --no-roofline --serial-streams > /dev/null 2> $R/gpurun_out/pmc_${TAG}_$i.err
 done
 python3 - <<PY
 import csv, glob, json, collections, os
