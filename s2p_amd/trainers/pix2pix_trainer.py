@@ -94,8 +94,7 @@ class Pix2PixTrainer:
         self.pix2pix_model.before_netD = self._wait_D_update if multi else None
         g_losses, generated = self.pix2pix_model(data, mode="generator")
         self.pix2pix_model.before_netD = None
-        g_loss = sum(g_losses.values()).mean()
-        g_loss.backward()                  # multi-rank: the tail all-reduce is launched from inside (on_early_grads)
+        self._backward(g_losses)           # multi-rank: the tail all-reduce is launched from inside (on_early_grads)
         if multi:
             self._finish_G_exchange()
         self.optimizer_G.step()
@@ -105,13 +104,21 @@ class Pix2PixTrainer:
     def run_discriminator_one_step(self, data):
         self.optimizer_D.zero_grad()
         d_losses = self.pix2pix_model(data, mode="discriminator")
-        d_loss = sum(d_losses.values()).mean()
-        d_loss.backward()
+        self._backward(d_losses)
         if self.dp.world_size > 1:
             self._cut(self._finish_D_async)
         else:
             self.optimizer_D.step()
         self.d_losses = d_losses
+
+    def _backward(self, losses):
+        """sum(losses.values()).mean().backward() without the adds / mean / their autograd kernels (~10 tiny launches per
+        call): every loss term is a 0-dim tensor and receives the upstream gradient 1 directly."""
+        vals = list(losses.values())
+        one = getattr(self, "_one", None)
+        if one is None or one.device != vals[0].device:
+            one = self._one = torch.ones((), dtype=vals[0].dtype, device=vals[0].device)
+        torch.autograd.backward(vals, [one] * len(vals))
 
     def sync(self):
         """Wait (on the current stream) for everything the trainer has in flight on the communication stream."""
