@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define S2P_VERSION 105
+#define S2P_VERSION 106
 
 enum { S2P_F32 = 0, S2P_BF16 = 1 };
 enum { S2P_ACT_NONE = 0, S2P_ACT_RELU = 1, S2P_ACT_LRELU = 2, S2P_ACT_TANH = 3, S2P_ACT_SWISH = 4 };
@@ -81,12 +81,19 @@ int s2p_conv2d_dgrad(const s2p_conv_desc* d, const void* dy, const void* w_bwd,
  * fused into the same pass over dy.                                                     */
 int s2p_conv2d_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, float* db,
                      int cin_real, int cout_real, int64_t dw_gstride, int splitk, void* stream);
+/* The same with a caller-owned device scratch of at least s2p_conv2d_wgrad_workspace(...) bytes: the K-split units of the
+ * bf16 kernels then store partial tiles there and a second kernel adds them to dw / db in a fixed order -- no atomics,
+ * bitwise reproducible (s2p_conv2d_wgrad itself, and a NULL / short workspace, accumulate with fp32 atomics).            */
+size_t s2p_conv2d_wgrad_workspace(const s2p_conv_desc* d, int cin_real, int cout_real);
+int s2p_conv2d_wgrad_ws(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, float* db,
+                        int cin_real, int cout_real, int64_t dw_gstride, int splitk, void* workspace,
+                        size_t workspace_bytes, void* stream);
 /* Batched weight gradient: n_jobs (<= 16) convolutions of the SAME geometry `d` (groups must be 1; a grouped conv is
  * passed as one job per group with offset pointers and the tensors' pitches in d->x_pitch / d->y_pitch) in ONE launch.
  * `jobs` is a HOST array (copied into the kernel arguments: safe under hipGraph capture).  dw / db are ACCUMULATED into,
  * as in s2p_conv2d_wgrad.  For bf16 3x3 stride-1 pad-1 convs with Cin, Cout multiples of 64 this runs the slab kernel
  * (csrc/wgrad_slab.hip): no atomics -- K-split partial tiles go to `workspace` and are summed in a fixed order, so the
- * result is bitwise reproducible; other geometries fall back to one s2p_conv2d_wgrad launch per job.
+ * result is bitwise reproducible; other geometries run one s2p_conv2d_wgrad_ws launch per job on the same workspace.
  * workspace: caller-owned device scratch of at least s2p_conv2d_wgrad_batched_workspace(...) bytes (may be 0).       */
 typedef struct { const void* x; const void* dy; float* dw; float* db; } s2p_wgrad_job;
 size_t s2p_conv2d_wgrad_batched_workspace(const s2p_conv_desc* d, int n_jobs, int cin_real, int cout_real);

@@ -131,6 +131,10 @@ bool s2p_thin_applicable(const s2p_conv_desc* d);
 int s2p_thin_fwd(const s2p_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int act, float slope,
                  hipStream_t st);
 int s2p_thin_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, int cin_real, hipStream_t st);
+// row-streaming thin-Cout kernels (thin_rows.hip)
+bool s2p_thin_rows_applicable(const s2p_conv_desc* d);
+int s2p_thin_rows_fwd(const s2p_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int act,
+                      float slope, hipStream_t st);
 // PatchGAN logit heads, Cout = 1 (wgrad_head.hip)
 bool s2p_head_wgrad_supported(const s2p_conv_desc* d, int cin_real, int cout_real);
 size_t s2p_head_wgrad_workspace(const s2p_conv_desc* d);

@@ -24,6 +24,10 @@ struct WgradArgs {
   long long dw_gstride; int dw_row;   // dW row length = T*Cb_real
   int splitk, steps_per_split;
   int na_tiles, nb_tiles;
+  // deterministic mode (DMA kernel): every (split, group) unit stores its partial tile sums to `part`
+  // [unit][part_rows][part_cols] (and bias partials to part_b [unit][part_rows]); wgrad_part_reduce_kernel adds them to
+  // dW / db in unit order.  part == nullptr: fp32 atomics straight into dW / db.
+  float* part; float* part_b; int part_rows, part_cols;
   int tap[64];
 };
 
@@ -365,6 +369,34 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
   const int r = lane & 31, h = lane >> 5;
   float* dWg = a.dW + (size_t)g * a.dw_gstride;
   if (S2P_DIAGV(a) == 3) return;
+  if (a.part) {
+    // plain stores of the partial tile: for a fixed register the 32 lanes of a half write 32 consecutive columns
+    const size_t unit = (size_t)split * a.groups + g;
+    float* P = a.part + unit * a.part_rows * a.part_cols;
+#pragma unroll
+    for (int j = 0; j < TT; ++j) {
+      const int n = b_tile * BT + wb0 + 32 * j + r;
+      if (n >= a.NB) continue;
+#pragma unroll
+      for (int i = 0; i < TT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int arow = a_tile * BT + wa0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (arow < a.Ca) P[(size_t)arow * a.part_cols + n] = acc[i][j][e];
+        }
+    }
+    if (do_bias && r == 0) {
+      float* PB = a.part_b + unit * a.part_rows;
+#pragma unroll
+      for (int i = 0; i < TT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int arow = a_tile * BT + wa0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (arow < a.Ca) PB[arow] = accb[i][e];
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TT; ++j) {
     int n = b_tile * BT + wb0 + 32 * j + r;
@@ -392,8 +424,122 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
   }
 }
 
+// dW[g][arow][t][c] += sum over the split units' partial tiles, db likewise, in unit order (no atomics: bitwise
+// reproducible).  64 outputs per workgroup; with many units (NSEG = 16) an output's partials are summed by 16 threads (a
+// sixteenth each, 8 loads in flight) and combined in segment order.
+template <int NSEG>
+__global__ __launch_bounds__(64 * NSEG) void wgrad_part_reduce_kernel(const WgradArgs a, int n_out, int n_bias) {
+  __shared__ float red[64 * NSEG];
+  const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const long long idx = (long long)blockIdx.x * 64 + o;           // [0, n_out): dW elements, then [n_out, n_out + n_bias): db
+  const int S = a.splitk;
+  const int per = (S + NSEG - 1) / NSEG;
+  const int k0 = sg * per, k1 = k0 + per < S ? k0 + per : S;
+  float s = 0.f;
+  float* dst = nullptr;
+  if (idx < (long long)n_out + n_bias) {
+    const float* p; size_t stride;
+    if (idx < n_out) {
+      const int per_g = a.Ca_real * a.dw_row;
+      const int g = (int)(idx / per_g), rem = (int)(idx - (long long)g * per_g);
+      const int arow = rem / a.dw_row, col = rem - arow * a.dw_row;
+      const int t = col / a.Cb_real, c = col - t * a.Cb_real;
+      p = a.part + ((size_t)g * a.part_rows + arow) * a.part_cols + t * a.Cb + c;
+      stride = (size_t)a.groups * a.part_rows * a.part_cols;
+      dst = a.dW + (size_t)g * a.dw_gstride + (size_t)arow * a.dw_row + col;
+    } else {
+      const int b = (int)(idx - n_out), g = b / a.Ca_real, arow = b - g * a.Ca_real;
+      p = a.part_b + (size_t)g * a.part_rows + arow;
+      stride = (size_t)a.groups * a.part_rows;
+      dst = a.db + b;
+    }
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < k1; ++k) s += p[(size_t)k * stride];
+  }
+  if (NSEG == 1) { if (dst) *dst += s; return; }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (sg == 0 && dst) {
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < NSEG; ++k) tot += red[64 * k + o];
+    *dst += tot;
+  }
+}
+
+// split count of the LDS-DMA kernels: (groups * splits) a multiple of 8 (one unit per XCD per round), enough workgroups
+// to fill the chip
+static void wgrad_dma_splits(WgradArgs& a, int groups, int target) {
+  const int tiles = a.na_tiles * a.nb_tiles;
+  const int total = cdiv(a.M, 32);
+  int U = 8 * (cdiv(target, tiles * 8) > 1 ? cdiv(target, tiles * 8) : 1);
+  int sk = cdiv(U, groups);
+  if (sk > total) sk = total;
+  if (sk < 1) sk = 1;
+  a.steps_per_split = cdiv(total, sk); a.splitk = cdiv(total, a.steps_per_split);
+  a.groups = groups;
+}
+
+static bool wgrad_dma_ok(const s2p_conv_desc* d) {
+  if (d->dtype != S2P_BF16) return false;
+  const long long pa = d->transposed ? (long long)d->N * d->H * d->W * d->x_pitch : (long long)d->N * d->Ho * d->Wo * d->y_pitch;
+  const long long pb = d->transposed ? (long long)d->N * d->Ho * d->Wo * d->y_pitch : (long long)d->N * d->H * d->W * d->x_pitch;
+  return pa * 2 < (1ll << 31) && pb * 2 < (1ll << 31);
+}
+
+// fills the geometry fields shared by the launch and the workspace query; returns false for shapes outside the DMA kernels
+static bool wgrad_dma_plan(const s2p_conv_desc* d, int cin_real, int cout_real, WgradArgs& a, bool& dense) {
+  const int ce = 8;
+  const int T = d->KH * d->KW;
+  const int cout_pad = (d->Cout + ce - 1) / ce * ce;
+  a.istride = d->stride; a.reflect = d->reflect; a.T = T;
+  if (!d->transposed) {        // A = dY on the output grid, B = X gathered
+    a.Qh = d->Ho; a.Qw = d->Wo; a.M = d->N * d->Ho * d->Wo;
+    a.Ca = cout_pad; a.a_pitch = d->y_pitch; a.a_gstride = d->y_gstride; a.Ca_real = cout_real;
+    a.Hi = d->H; a.Wi = d->W; a.Cb = d->Cin; a.b_pitch = d->x_pitch; a.b_gstride = d->x_gstride;
+    a.Cb_real = cin_real;
+  } else {                     // A = X on the input grid, B = dY gathered at iy*s + ky - pad
+    a.Qh = d->H; a.Qw = d->W; a.M = d->N * d->H * d->W;
+    a.Ca = d->Cin; a.a_pitch = d->x_pitch; a.a_gstride = d->x_gstride; a.Ca_real = cin_real;
+    a.Hi = d->Ho; a.Wi = d->Wo; a.Cb = cout_pad; a.b_pitch = d->y_pitch; a.b_gstride = d->y_gstride;
+    a.Cb_real = cout_real;
+  }
+  a.NB = T * a.Cb; a.dw_row = T * a.Cb_real;
+  a.na_tiles = cdiv(a.Ca, 128); a.nb_tiles = cdiv(a.NB, 128);
+  dense = a.a_pitch <= 1024 && a.b_pitch <= 1024;
+  if (!wgrad_dma_ok(d) || s2p_env_set("S2P_NO_LDS_DMA")) return false;
+  if (!dense && s2p_env_set("S2P_NO_WGRAD_WIDE_DMA")) return false;
+  wgrad_dma_splits(a, d->groups, dense ? s2p_env_int("S2P_WGRAD_BLOCKS", 384) : 384);
+  a.part_rows = a.na_tiles * 128; a.part_cols = a.nb_tiles * 128;
+  return true;
+}
+
+extern "C" size_t s2p_conv2d_wgrad_workspace(const s2p_conv_desc* d, int cin_real, int cout_real) {
+  if (!d || d->dtype != S2P_BF16 || d->KH * d->KW > 64) return 0;
+  if (s2p_thin_applicable(d) && cout_real == d->Cout) return 0;
+  WgradArgs a{};
+  bool dense;
+  if (!wgrad_dma_plan(d, cin_real, cout_real, a, dense)) return 0;
+  if (a.splitk * a.groups <= 1) return 0;
+  const size_t units = (size_t)a.splitk * a.groups;
+  return units * a.part_rows * ((size_t)a.part_cols + 1) * sizeof(float);
+}
+
 extern "C" int s2p_conv2d_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, float* db,
                                 int cin_real, int cout_real, int64_t dw_gstride, int splitk, void* stream) {
+  return s2p_conv2d_wgrad_ws(d, x, dy, dw, db, cin_real, cout_real, dw_gstride, splitk, nullptr, 0, stream);
+}
+
+extern "C" int s2p_conv2d_wgrad_ws(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, float* db,
+                                   int cin_real, int cout_real, int64_t dw_gstride, int splitk, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
   if (!d || !x || !dy || !dw) S2P_FAIL(-1, "s2p_conv2d_wgrad: null pointer");
   if (d->dtype != S2P_F32 && d->dtype != S2P_BF16) S2P_FAIL(-1, "s2p_conv2d_wgrad: bad dtype");
   const int ce = d->dtype == S2P_F32 ? 4 : 8;
@@ -408,6 +554,57 @@ extern "C" int s2p_conv2d_wgrad(const s2p_conv_desc* d, const void* x, const voi
     if (db) { int rc = s2p_channel_sum(d->dtype, dy, (int64_t)d->N * d->Ho * d->Wo, cout_real, d->y_pitch, db, stream); if (rc) return rc; }
     return s2p_thin_wgrad(d, x, dy, dw, cin_real, (hipStream_t)stream);
   }
+  hipStream_t st = (hipStream_t)stream;
+  {
+    // bf16, tensors < 2 GiB: LDS-DMA kernels.  With a workspace (s2p_conv2d_wgrad_workspace) the split units store
+    // partial tiles and a second kernel adds them in unit order: no atomics, bitwise reproducible, and no 16-fold
+    // read-modify-write traffic on dW; without one the units add to dW with fp32 atomics.
+    WgradArgs a{};
+    bool dense = true;
+    if (d->dtype == S2P_BF16 && wgrad_dma_plan(d, cin_real, cout_real, a, dense)) {
+      a.dW = dw; a.dw_gstride = dw_gstride;
+      a.A = d->transposed ? x : dy; a.B = d->transposed ? dy : x;
+      for (int ky = 0; ky < d->KH; ++ky)
+        for (int kx = 0; kx < d->KW; ++kx)
+          a.tap[ky * d->KW + kx] = (((kx - d->pad) & 0xff) << 8) | ((ky - d->pad) & 0xff);
+      a.a_bytes = (unsigned)((long long)d->N * a.Qh * a.Qw * a.a_pitch * 2);
+      a.b_bytes = (unsigned)((long long)d->N * a.Hi * a.Wi * a.b_pitch * 2);
+      static const int diag = s2p_env_int("S2P_DIAG", 0);
+      a.diag = diag;
+      // Large-pitch (grouped / channel-sliced) operands: these launches are L2-latency-bound and live on occupancy, so
+      // they take the 2-stage DMA kernel without the fused bias accumulators (126 VGPRs, 32 KiB LDS: 4 workgroups per CU;
+      // the 3-stage + fused-bias form is 146 VGPRs / 48 KiB = 3 per CU and measured 930 us on the 12-group gamma/beta
+      // wgrad, the register-staged kernel 670 us, this form 521 us).  The bias gradient is a separate channel-sum pass.
+      if (!dense && db) {
+        int rc = s2p_channel_sum(d->dtype, dy, (int64_t)d->N * d->Ho * d->Wo, cout_real * d->groups, d->y_pitch, db, stream);
+        if (rc) return rc;
+      }
+      a.db = dense ? db : nullptr;              // dense: fused bias gradient (groups: db is [groups][Cout])
+      const int units = a.groups * a.splitk;
+      const size_t need = s2p_conv2d_wgrad_workspace(d, cin_real, cout_real);
+      const bool det = units > 1 && workspace && workspace_bytes >= need && need > 0;
+      if (det) {
+        a.part = (float*)workspace;
+        a.part_b = a.part + (size_t)units * a.part_rows * a.part_cols;
+      }
+      const int tiles = a.na_tiles * a.nb_tiles;
+      dim3 grid1(8 * tiles * cdiv(units, 8));
+      if (dense) hipLaunchKernelGGL(wgrad_dma_kernel<32>, grid1, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((wgrad_dma_kernel<32, 2, false>), grid1, dim3(256), 0, st, a);
+      S2P_CHECK_LAUNCH("wgrad_dma_kernel");
+      if (det) {
+        const long long n_out = (long long)a.groups * a.Ca_real * a.dw_row;
+        const int n_bias = a.db ? a.groups * a.Ca_real : 0;
+        if (n_out >= (1ll << 31)) S2P_FAIL(-2, "s2p_conv2d_wgrad: dW too large");
+        const int nblk = cdiv(n_out + n_bias, 64);
+        if (a.splitk > 16) hipLaunchKernelGGL(wgrad_part_reduce_kernel<16>, dim3(nblk), dim3(1024), 0, st, a, (int)n_out, n_bias);
+        else hipLaunchKernelGGL(wgrad_part_reduce_kernel<1>, dim3(nblk), dim3(64), 0, st, a, (int)n_out, n_bias);
+        S2P_CHECK_LAUNCH("wgrad_part_reduce_kernel");
+      }
+      return 0;
+    }
+  }
+  // fp32 (exact MFMA path) and bf16 tensors beyond the buffer-descriptor range: register-staged kernel, fp32 atomics
   WgradArgs a{};
   a.dW = dw; a.db = nullptr;
   a.istride = d->stride; a.reflect = d->reflect; a.T = T;
@@ -440,60 +637,12 @@ extern "C" int s2p_conv2d_wgrad(const s2p_conv_desc* d, const void* x, const voi
   a.steps_per_split = cdiv(total_steps, splitk);
   a.splitk = cdiv(total_steps, a.steps_per_split);
   dim3 grid(a.na_tiles * a.nb_tiles, d->groups, a.splitk);
-  hipStream_t st = (hipStream_t)stream;
-  const long long abytes = (long long)d->N * a.Qh * a.Qw * a.a_pitch * 2, bbytes = (long long)d->N * a.Hi * a.Wi * a.b_pitch * 2;
-  static const int no_dma = s2p_env_set("S2P_NO_LDS_DMA");
-  const bool dense = a.a_pitch <= 1024 && a.b_pitch <= 1024;
-  // Large-pitch (grouped / channel-sliced) operands: these launches are L2-latency-bound and live on occupancy, so they
-  // take the 2-stage DMA kernel without the fused bias accumulators (126 VGPRs, 32 KiB LDS: 4 workgroups per CU; the
-  // 3-stage + fused-bias form is 146 VGPRs / 48 KiB = 3 per CU and measured 930 us on the 12-group gamma/beta wgrad,
-  // the register-staged kernel 670 us, this form 521 us).  The bias gradient is a separate channel-sum pass here.
-  static const int wide_dma = (s2p_env_set("S2P_NO_WGRAD_WIDE_DMA") ? 0 : 1);
-  if (d->dtype == S2P_BF16 && !no_dma && !dense && wide_dma && abytes < (1ll << 31) && bbytes < (1ll << 31)) {
-    a.a_bytes = (unsigned)abytes; a.b_bytes = (unsigned)bbytes;
-    a.db = nullptr;
-    if (db) { int rc = s2p_channel_sum(d->dtype, dy, (int64_t)d->N * d->Ho * d->Wo, cout_real * d->groups, d->y_pitch, db, stream); if (rc) return rc; }
-    const int tiles = a.na_tiles * a.nb_tiles;
-    const int total = cdiv(a.M, 32);
-    const int target = 384;
-    int U = 8 * (cdiv(target, tiles * 8) > 1 ? cdiv(target, tiles * 8) : 1);
-    int sk = cdiv(U, d->groups);
-    if (sk > total) sk = total;
-    if (sk < 1) sk = 1;
-    a.steps_per_split = cdiv(total, sk); a.splitk = cdiv(total, a.steps_per_split);
-    a.groups = d->groups;
-    const int units = a.groups * a.splitk;
-    dim3 grid1(8 * tiles * cdiv(units, 8));
-    hipLaunchKernelGGL((wgrad_dma_kernel<32, 2, false>), grid1, dim3(256), 0, st, a);
-    S2P_CHECK_LAUNCH("wgrad_dma_kernel");
-    return 0;
+  if (db) {
+    int rc = s2p_channel_sum(d->dtype, dy, (int64_t)d->N * d->Ho * d->Wo, cout_real * d->groups, d->y_pitch, db, stream);
+    if (rc) return rc;
   }
-  if (d->dtype == S2P_BF16 && !no_dma && dense && abytes < (1ll << 31) && bbytes < (1ll << 31)) {
-    a.a_bytes = (unsigned)abytes; a.b_bytes = (unsigned)bbytes;
-    static const int diag = s2p_env_int("S2P_DIAG", 0);
-    a.diag = diag;
-    a.db = db;                                  // fused bias gradient (groups: db is [groups][Cout])
-    static const int target = s2p_env_int("S2P_WGRAD_BLOCKS", 384);
-    // split count: (groups * splits) a multiple of 8 (one unit per XCD per round), enough workgroups to fill the chip
-    const int tiles = a.na_tiles * a.nb_tiles;
-    const int total = cdiv(a.M, 32);
-    int U = 8 * (cdiv(target, tiles * 8) > 1 ? cdiv(target, tiles * 8) : 1);
-    int sk = cdiv(U, d->groups);
-    if (sk > total) sk = total;
-    if (sk < 1) sk = 1;
-    a.steps_per_split = cdiv(total, sk); a.splitk = cdiv(total, a.steps_per_split);
-    a.groups = d->groups;
-    const int units = a.groups * a.splitk;
-    dim3 grid1(8 * tiles * cdiv(units, 8));
-    hipLaunchKernelGGL(wgrad_dma_kernel<32>, grid1, dim3(256), 0, st, a);
-  } else {
-    if (db) {
-      int rc = s2p_channel_sum(d->dtype, dy, (int64_t)d->N * d->Ho * d->Wo, cout_real * d->groups, d->y_pitch, db, stream);
-      if (rc) return rc;
-    }
-    if (d->dtype == S2P_F32) hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(wgrad_kernel<__bf16>, grid, dim3(256), 0, st, a);
-  }
+  if (d->dtype == S2P_F32) hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(wgrad_kernel<__bf16>, grid, dim3(256), 0, st, a);
   S2P_CHECK_LAUNCH("wgrad_kernel");
   return 0;
 }

@@ -294,7 +294,8 @@ static int ws_splits(const s2p_conv_desc* d, int n_jobs) {
 
 extern "C" size_t s2p_conv2d_wgrad_batched_workspace(const s2p_conv_desc* d, int n_jobs, int cin_real, int cout_real) {
   if (d && n_jobs >= 1 && s2p_head_wgrad_supported(d, cin_real, cout_real)) return (size_t)n_jobs * s2p_head_wgrad_workspace(d);
-  if (!d || !ws_supported(d, n_jobs, cin_real, cout_real)) return 0;
+  if (!d) return 0;
+  if (!ws_supported(d, n_jobs, cin_real, cout_real)) return s2p_conv2d_wgrad_workspace(d, cin_real, cout_real);   // jobs run one after the other
   const int S = ws_splits(d, n_jobs);
   if (S == 1) return 0;
   const size_t tiles = (size_t)n_jobs * (d->Cout / 64) * (d->Cin / 64);
@@ -318,9 +319,11 @@ extern "C" int s2p_conv2d_wgrad_batched(const s2p_conv_desc* d, const s2p_wgrad_
     return 0;
   }
   if (!ws_supported(d, n_jobs, cin_real, cout_real)) {
-    // geometry outside the slab kernel's scope (other taps / strides / dtypes): one generic launch per job
+    // geometry outside the slab kernel's scope (other taps / strides / dtypes): one generic launch per job, stream-ordered
+    // on the same workspace
     for (int j = 0; j < n_jobs; ++j) {
-      int rc = s2p_conv2d_wgrad(d, jobs[j].x, jobs[j].dy, jobs[j].dw, jobs[j].db, cin_real, cout_real, 0, 0, stream);
+      int rc = s2p_conv2d_wgrad_ws(d, jobs[j].x, jobs[j].dy, jobs[j].dw, jobs[j].db, cin_real, cout_real, 0, 0, workspace,
+                                   workspace_bytes, stream);
       if (rc) return rc;
     }
     return 0;

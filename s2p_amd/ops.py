@@ -143,12 +143,15 @@ def conv_dgrad(geom, dy, w_bwd, x_shape, cin_pad, aux=None, epi=EPI_STORE, aux_a
 
 
 def conv_wgrad(geom, x, dy, dw, cin_pad, cin_real, cout_real, dw_gstride=0, splitk=0, db=None):
-    """dw += wgrad (cudnn_convolution_backward_weight equivalent); dw is an fp32 view in channels-last layout."""
+    """dw += wgrad (cudnn_convolution_backward_weight equivalent); dw is an fp32 view in channels-last layout.
+    The K-split partial sums go through a scratch buffer and are added in a fixed order (s2p_conv2d_wgrad_ws): no atomics."""
     N, H, W, xp = x.shape
     d = geom.desc(x.dtype, N, H, W, cin_pad, xp, dy.shape[3])
+    need = lib().s2p_conv2d_wgrad_workspace(ctypes.byref(d), cin_real, cout_real)
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
     pr = _Prof("wgrad", geom, N, H, W, x.dtype)
-    check(lib().s2p_conv2d_wgrad(ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db), cin_real, cout_real, dw_gstride, splitk,
-                                 stream()), "s2p_conv2d_wgrad")
+    check(lib().s2p_conv2d_wgrad_ws(ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db), cin_real, cout_real, dw_gstride, splitk,
+                                    ptr(ws), need, stream()), "s2p_conv2d_wgrad_ws")
     pr.done()
 
 

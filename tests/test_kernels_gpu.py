@@ -2,6 +2,7 @@
 Integer/index work (pool routing, layout) must be exact; fp32 kernels (exact-fp32 MFMA path) within 1e-5 of the
 float64 result -- 100x tighter than north_star's 1e-3, so that a kernel that loses precision cannot hide behind
 ReLU-kink arguments at model level; bf16 kernels within 2e-2 of the fp32 result of bf16-rounded inputs."""
+import ctypes
 import math
 
 import pytest
@@ -11,7 +12,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from s2p_amd import ops  # noqa: E402
-from s2p_amd._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, EPI_ADD, EPI_MUL_ACTGRAD, EPI_STORE, chunk_elems
+from s2p_amd._lib import lib, ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, EPI_ADD, EPI_MUL_ACTGRAD, EPI_STORE, chunk_elems
 
 
 def nhwc(x, pitch, dtype, dev):
@@ -61,6 +62,9 @@ CONV_CASES = [
     (64, 160, 5, 1, 2, False, False, 17, 23, 2),   # halo-resident path, 5x5 taps, ragged Cout tile
     (64, 3, 7, 1, 3, False, True, 40, 36, 2),      # out conv at a size that takes the spatially tiled MFMA path (ragged tiles)
     (32, 2, 5, 1, 2, False, False, 33, 37, 1),     # tiled path, zero padding, Cout=2, K=5
+    (64, 3, 7, 1, 3, False, True, 84, 84, 2),      # out conv, row-streaming path: 3 waves, several row bands
+    (64, 3, 7, 1, 3, False, True, 9, 130, 1),      # row-streaming path: two column strips, one short band
+    (64, 3, 7, 1, 3, False, False, 30, 40, 3),     # row-streaming path with zero padding
 ]
 
 
@@ -399,6 +403,54 @@ def test_conv_wgrad_batched_slab(hip_device, case):
             assert torch.equal(db[j], db0[j])
     dw2, db2 = run()
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+@pytest.mark.parametrize("case", [
+    # cin, cout, k, stride, pad, transposed, H, W, N
+    (6, 64, 4, 2, 2, False, 42, 42, 8),        # PatchGAN first layer: one tile, hundreds of split units (16-segment reduce)
+    (256, 512, 4, 1, 2, False, 7, 7, 8),       # PatchGAN 256->512: 128 tiles, 8 units
+    (128, 64, 3, 2, 1, True, 12, 12, 4),       # up conv (transposed form, no bias gradient)
+    (64, 128, 3, 2, 1, False, 20, 20, 4),      # down conv
+])
+def test_conv_wgrad_split_units_deterministic(hip_device, case):
+    """s2p_conv2d_wgrad_ws: the K-split units of the LDS-DMA weight-gradient kernel store partial tiles and a second
+    kernel adds them in unit order -- float64 parity, accumulation into a non-zero dw / db, bitwise reproducibility."""
+    cin, cout, k, s, p, tr, H, W, N = case
+    dev, dtype = hip_device, torch.bfloat16
+    g = torch.Generator().manual_seed(11 + cin)
+    x = torch.randn(N, cin, H, W, generator=g).bfloat16().float()
+    geom = ops.ConvGeom(cin, cout, k, s, p, transposed=tr, output_padding=1 if tr else 0)
+    Ho, Wo = geom.out_hw(H, W)
+    dy = torch.randn(N, cout, Ho, Wo, generator=g).bfloat16().float()
+    cin_pad, cout_pad = ops.pad_to(cin, 8), ops.pad_to(cout, 8)
+    xd, dyd = nhwc(x, cin_pad, dtype, dev), nhwc(dy, cout_pad, dtype, dev)
+    rows, cols = (cin, cout) if tr else (cout, cin)
+    dw0 = torch.randn(rows, k * k, cols, generator=g)
+    db0 = torch.randn(cout, generator=g)
+    d = geom.desc(dtype, N, H, W, cin_pad, cin_pad, cout_pad)
+    assert lib().s2p_conv2d_wgrad_workspace(ctypes.byref(d), cin, cout) > 0          # the deterministic path is the one tested
+
+    def run():
+        dw = dw0.clone().to(dev); db = None if tr else db0.clone().to(dev)
+        ops.conv_wgrad(geom, xd, dyd, dw, cin_pad, cin, cout, db=db)
+        torch.cuda.synchronize()
+        return dw.cpu(), (None if tr else db.cpu())
+
+    dw, db = run()
+    xr = x.double()
+    wr = torch.zeros((cin, cout, k, k) if tr else (cout, cin, k, k), dtype=torch.float64, requires_grad=True)
+    if tr:
+        F.conv_transpose2d(xr, wr, stride=s, padding=p, output_padding=1).backward(dy.double())
+    else:
+        F.conv2d(xr, wr, stride=s, padding=p).backward(dy.double())
+    ref = dw0.double() + wr.grad.permute(0, 2, 3, 1).reshape(rows, k * k, cols)
+    assert rel_err(dw, ref) < 1e-5
+    if not tr:
+        assert rel_err(db, db0.double() + dy.double().sum((0, 2, 3))) < 1e-5
+    dw2, db2 = run()
+    assert torch.equal(dw, dw2)
+    if not tr:
+        assert torch.equal(db, db2)
 
 
 @pytest.mark.parametrize("case", [(512, 4, 13, 13, 5), (128, 4, 8, 7, 3), (64, 3, 9, 9, 2)])
