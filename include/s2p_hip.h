@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define S2P_VERSION 106
+#define S2P_VERSION 107
 
 enum { S2P_F32 = 0, S2P_BF16 = 1 };
 enum { S2P_ACT_NONE = 0, S2P_ACT_RELU = 1, S2P_ACT_LRELU = 2, S2P_ACT_TANH = 3, S2P_ACT_SWISH = 4 };
@@ -73,6 +73,19 @@ int s2p_conv2d_fwd(const s2p_conv_desc* d, const void* x, const void* w_fwd, con
 int s2p_conv2d_dgrad(const s2p_conv_desc* d, const void* dy, const void* w_bwd,
                      const void* aux, const void* aux2, void* dx, int epi, int aux_act, float slope,
                      void* stream);
+/* s2p_conv2d_fwd / s2p_conv2d_dgrad with a caller-owned device scratch of at least s2p_conv2d_{fwd,dgrad}_workspace(...)
+ * bytes (0 for most shapes).  bf16 launches that cannot fill the chip (<= 160 workgroups: small maps with a long K, e.g.
+ * the PatchGAN 256->512 layers on 7x7 / 12x12 maps) then split K over the idle CUs: every slice stores an fp32 partial
+ * tile to the scratch and a second kernel applies bias / activation / epilogue to their fixed-order sum (no atomics;
+ * bitwise reproducible).  A NULL / short workspace runs the unsplit kernels: same result up to fp32 summation order.   */
+size_t s2p_conv2d_fwd_workspace(const s2p_conv_desc* d, int epi);
+int s2p_conv2d_fwd_ws(const s2p_conv_desc* d, const void* x, const void* w_fwd, const float* bias,
+                      const void* aux, void* y, int act, float slope, int epi, void* workspace,
+                      size_t workspace_bytes, void* stream);
+size_t s2p_conv2d_dgrad_workspace(const s2p_conv_desc* d);
+int s2p_conv2d_dgrad_ws(const s2p_conv_desc* d, const void* dy, const void* w_bwd,
+                        const void* aux, const void* aux2, void* dx, int epi, int aux_act, float slope,
+                        void* workspace, size_t workspace_bytes, void* stream);
 /* dw (fp32) [groups][Cout][KH*KW][Cin_real] for transposed==0,
  *           [groups][Cin][KH*KW][Cout_real] for transposed==1  (= channels-last physical
  * layout of the torch parameter).  dw is ACCUMULATED into (caller zeroes it);

@@ -44,6 +44,10 @@ SIGNATURES = {
     "s2p_last_error": [],
     "s2p_conv2d_fwd": [_DESC, _P, _P, _P, _P, _P, c_int, c_float, c_int, _P],
     "s2p_conv2d_dgrad": [_DESC, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P],
+    "s2p_conv2d_fwd_workspace": [_DESC, c_int],
+    "s2p_conv2d_fwd_ws": [_DESC, _P, _P, _P, _P, _P, c_int, c_float, c_int, _P, ctypes.c_size_t, _P],
+    "s2p_conv2d_dgrad_workspace": [_DESC],
+    "s2p_conv2d_dgrad_ws": [_DESC, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P, ctypes.c_size_t, _P],
     "s2p_conv2d_wgrad": [_DESC, _P, _P, _P, _P, c_int, c_int, c_int64, c_int, _P],
     "s2p_conv2d_wgrad_workspace": [_DESC, c_int, c_int],
     "s2p_conv2d_wgrad_ws": [_DESC, _P, _P, _P, _P, c_int, c_int, c_int64, c_int, _P, ctypes.c_size_t, _P],
@@ -92,7 +96,7 @@ SIGNATURES = {
     "s2p_copy_channels": [c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int64, c_int, _P],
     "s2p_image_metrics": [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P],
 }
-_RESTYPE = {"s2p_last_error": ctypes.c_char_p, "s2p_conv2d_wgrad_batched_workspace": ctypes.c_size_t, "s2p_conv2d_wgrad_workspace": ctypes.c_size_t, "s2p_linear_bwd_workspace": ctypes.c_size_t, "s2p_in_stats_floats": c_int64, "s2p_in_bwd_sums_floats": c_int64}
+_RESTYPE = {"s2p_last_error": ctypes.c_char_p, "s2p_conv2d_wgrad_batched_workspace": ctypes.c_size_t, "s2p_conv2d_wgrad_workspace": ctypes.c_size_t, "s2p_conv2d_fwd_workspace": ctypes.c_size_t, "s2p_conv2d_dgrad_workspace": ctypes.c_size_t, "s2p_linear_bwd_workspace": ctypes.c_size_t, "s2p_in_stats_floats": c_int64, "s2p_in_bwd_sums_floats": c_int64}
 
 _lib = None
 
@@ -119,7 +123,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the export is missing
             fn.argtypes = args
             fn.restype = _RESTYPE.get(name, c_int)
-        if L.s2p_version() < 106:
+        if L.s2p_version() < 107:
             raise RuntimeError("libs2p_hip.so is older than this package")
         _lib = L
     return _lib

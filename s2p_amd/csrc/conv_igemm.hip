@@ -32,6 +32,12 @@ struct GatherArgs {
   int halo_lo, halo_hi;        // halo kernel: pixels needed before / after the tile in raster order
   int diag;                    // timing-only ablation (S2P_DIAG env): 1 = skip in-loop loads, 2 = skip MFMAs
   int splitk, ksteps;          // generic fp32 path only: split-K over blockIdx.z with fp32 atomics into a zeroed y
+  // bf16 LDS-DMA kernel, launches that cannot fill the chip: K split over blockIdx.z into `psplit` slices of `psteps` K
+  // steps; each slice stores its fp32 partial tile to part[z][co][m] (m padded to part_m) and conv_part_reduce_kernel
+  // applies bias / activation / epilogue to the sum (fixed order: no atomics).  ws / ws_bytes: caller's scratch.
+  float* part; int psplit, psteps, part_m;
+  void* ws; size_t ws_bytes;
+  size_t* plan;                // non-null: dry run -- report the scratch bytes this launch would use, launch nothing
   unsigned x_bytes, w_bytes;   // fast path: buffer-descriptor sizes of the gathered tensor / packed weights (per group view)
   int tap[MAX_TAPS];   // (wt << 16) | ((dx & 0xff) << 8) | (dy & 0xff)
   // merged sub-pixel phases (strided dgrad / transposed fwd on the LDS-DMA kernel): blockIdx.z selects a record that
@@ -484,6 +490,7 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const GatherArgs a) {
 // ------------------------------------------------------------------------------------------------
 template <typename T, int BCO, int BPIX, int WCO, int WPIX>
 static int launch_cfg(GatherArgs& a, int groups, hipStream_t st) {
+  if (a.plan) return 0;
   a.npix_tiles = cdiv(a.M, BPIX);
   a.nco_tiles = cdiv(a.Cst, BCO);
   int splits = 1;
@@ -600,8 +607,15 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const GatherArgs a) {
     p_byte[i] = byte; p_mask[i] = mask;
   }
 
-  const int nk = pKtot / BK;
+  int nk = pKtot / BK;
   int tap = 0, c0 = 0;                                // block-uniform K position
+  if (a.psplit > 1) {                                 // this workgroup's K slice (blockIdx.z; never combined with phases)
+    const int kt0 = (int)blockIdx.z * a.psteps;
+    const int kt1 = kt0 + a.psteps < nk ? kt0 + a.psteps : nk;
+    const int k0 = kt0 * BK;
+    tap = k0 / a.Cin; c0 = k0 - tap * a.Cin;
+    nk = kt1 - kt0;
+  }
   typedef __attribute__((address_space(3))) void* lds_ptr;
 
   auto issue = [&](int buf) {
@@ -660,7 +674,82 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const GatherArgs a) {
     }
     __syncthreads();
   }
+  if (a.psplit > 1) {
+    // partial tile, [co][m]: for a fixed register the 32 lanes of a half store 32 consecutive pixels
+    float* P = a.part + (size_t)blockIdx.z * a.Cst * a.part_m;
+#pragma unroll
+    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+      for (int j = 0; j < TPIX; ++j) {
+        const int m = pix_base + wpix0 + 32 * j + r;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int co = co_base + wco0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (co < a.Cst) P[(size_t)co * a.part_m + m] = acc[i][j][e];
+        }
+      }
+    return;
+  }
   conv_epilogue<T, BCO, BPIX, TCO, TPIX>(a, acc, smem, rowoff, g, co_base, wco0, wpix0, r, h, tid);
+}
+
+// y[m][co] = epilogue(bias[co] + sum_z part[z][co][m]) for the K-split launches of conv_dma_kernel: the same bias /
+// activation / residual / producer-activation-gradient semantics as conv_epilogue, element by element.  One thread per
+// (pixel, 8-channel chunk), pixels fastest: the partial reads are coalesced, the 16-B stores land in L2.
+__global__ __launch_bounds__(256) void conv_part_reduce_kernel(const GatherArgs a) {
+  typedef __bf16 T;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int nch = (a.Cst + 7) / 8;
+  if (idx >= (long long)a.M * nch) return;
+  const int ch = (int)(idx / a.M), m = (int)(idx - (long long)ch * a.M);
+  const int co0 = ch * 8;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (a.bias && co0 + e < a.Cout) ? a.bias[co0 + e] : 0.f;
+  const size_t zs = (size_t)a.Cst * a.part_m;
+  for (int z = 0; z < a.psplit; ++z) {
+    const float* P = a.part + z * zs + (size_t)co0 * a.part_m + m;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (co0 + e < a.Cst) v[e] += P[(size_t)e * a.part_m];
+  }
+  const float ns = a.act == S2P_ACT_RELU ? 0.f : (a.act == S2P_ACT_LRELU ? a.slope : 1.f);
+  const bool act_generic = (a.act == S2P_ACT_TANH || a.act == S2P_ACT_SWISH);
+  Chunk<T> c; c.raw = (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float t = v[e];
+    const float w = act_generic ? (a.act == S2P_ACT_TANH ? tanhf(t) : t / (1.f + expf(-t))) : (t > 0.f ? t : t * ns);
+    c.set(e, w);                                       // rounded to bf16 here, as the fused epilogue does before epi
+  }
+  const size_t go = (size_t)m * a.y_pitch + co0;        // same grid, stride 1: output pixel index == GEMM pixel index
+  const bool full = co0 + 8 <= a.Cst;
+  T* y = (T*)a.y;
+  if (a.epi != S2P_EPI_STORE) {
+    const T* aux = (const T*)a.aux; const T* aux2 = (const T*)a.aux2;
+    const bool epi_add = a.epi == S2P_EPI_ADD;
+    const bool g_tanh = a.gact == S2P_ACT_TANH;
+    const float gneg = a.gact == S2P_ACT_RELU ? 0.f : (a.gact == S2P_ACT_LRELU ? a.gslope : 1.f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (co0 + e < a.Cst) {
+        const float xv = to_f32(aux[go + e]);
+        const float x2 = aux2 ? to_f32(aux2[go + e]) : 0.f;
+        const float f = g_tanh ? 1.f - xv * xv : (xv > 0.f ? 1.f : gneg);
+        c.set(e, epi_add ? c.get(e) + xv : (c.get(e) + x2) * f);
+      }
+  }
+  if (full) *(u32x4*)(y + go) = c.raw;
+  else for (int e = 0; e < 8; ++e) if (co0 + e < a.Cst) y[go + e] = from_f32<T>(c.get(e));
+}
+
+// K-split plan of a single-phase bf16 launch (1 = no split): only launches of <= 160 workgroups, >= 16 K steps per slice
+static int conv_split_plan(int nwg, int nk) {
+  if (nwg > 160 || nk < 32) return 1;
+  int S = 384 / nwg;
+  if (S > nk / 16) S = nk / 16;
+  if (S > 16) S = 16;
+  return S < 2 ? 1 : S;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -688,6 +777,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
   char* hbase = smem;
   char* wbase = smem + NHB * HALO;
   char* zrow = smem + NHB * HALO + 2 * WSTAGE;
+  // diagnostics build, S2P_DIAG=9: the launch runs normally and stamps s_memrealtime (100 MHz) at entry / loop start / loop
+  // end / after the epilogue into `aux` (a debug buffer of its own: 4 x u64 per workgroup; epi must be STORE)
+  unsigned long long tl0 = 0, tl1 = 0, tl2 = 0;
+  if (S2P_DIAGV(a) == 9) tl0 = __builtin_amdgcn_s_memrealtime();
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -880,6 +973,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
     if (S2P_DIAGV(a) == 3) return;
     unsigned long long st_c0 = 0, st_r0 = 0;
     if (S2P_DIAGV(a) == 8) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+    if (S2P_DIAGV(a) == 9) tl1 = __builtin_amdgcn_s_memrealtime();
     read_frags(std::integral_constant<int, 0>{}, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, hbase);
     int hs = 0;
     for (int slab = 0; slab < nslab; ++slab) {
@@ -935,6 +1029,18 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
     if (S2P_DIAGV(a) == 4) { if (acc[0][0][0] == 12345.678f) ((float*)a.y)[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1]; return; }
+    if (S2P_DIAGV(a) == 9) {
+      tl2 = __builtin_amdgcn_s_memrealtime();
+      GatherArgs b = a; b.aux = nullptr;
+      conv_epilogue<T, BCO, BPIX, TCO, TPIX>(b, acc, smem, rowoff, g, co_base, wco0, wpix0, r, h, tid);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0 && g == 0 && a.aux) {
+        unsigned long long* o = (unsigned long long*)a.aux + (size_t)blockIdx.x * 4;
+        o[0] = tl0; o[1] = tl1; o[2] = tl2; o[3] = __builtin_amdgcn_s_memrealtime();
+      }
+      return;
+    }
     conv_epilogue<T, BCO, BPIX, TCO, TPIX>(a, acc, smem, rowoff, g, co_base, wco0, wpix0, r, h, tid);
     return;
   } else if constexpr (TS > 0) {
@@ -1104,6 +1210,7 @@ static int launch_fast(GatherArgs& a, int groups, hipStream_t st) {
   if constexpr (BCO == 128 && BPIX == 128) {
     if (!no_dma && !no_halo && a.istride == 1 && a.ostride == 1 && a.Qh == a.Hi && a.Qw == a.Wi && a.Ho == a.Qh &&
         a.Wo == a.Qw && a.T >= 4) {
+      if (a.plan) return 0;                              // halo-resident kernels: no scratch
       int lo = 0, hi = 0;
       for (int t = 0; t < a.T; ++t) {
         int off = (int)(signed char)(a.tap[t] & 0xff) * a.Wi + (int)(signed char)((a.tap[t] >> 8) & 0xff);
@@ -1126,6 +1233,34 @@ static int launch_fast(GatherArgs& a, int groups, hipStream_t st) {
       if (npos <= 320) { hipLaunchKernelGGL((conv_halo_kernel<320, false>), grid, dim3(256), 0, st, a); S2P_CHECK_LAUNCH("conv_halo_kernel"); return 0; }
     }
   }
+  // launches that cannot fill the chip (<= 160 workgroups, size-changing convs with a long K: PatchGAN 256->512 4x4 on 7x7 / 12x12 maps):
+  // K split over blockIdx.z + fixed-order reduce with the epilogue, when the caller passed a scratch buffer.  One
+  // workgroup alone on a CU is bound by its LDS-DMA issue rate (~0.7 us per 32 KiB K step), so the K loop is spread
+  // over the idle CUs instead.
+  static const int no_split = s2p_env_set("S2P_NO_CONV_SPLITK");
+  if (!no_dma && !no_split && groups == 1 && a.nphase == 0 && a.ostride == 1 && a.oy0 == 0 && a.ox0 == 0 && a.Qh == a.Ho &&
+      a.Qw == a.Wo && a.epi != S2P_EPI_ADD && (a.plan || a.ws)) {
+    const int nk = a.Ktot / 64;
+    const int S = conv_split_plan((int)grid.x, nk);
+    if (S > 1) {
+      a.psteps = cdiv(nk, S); a.psplit = cdiv(nk, a.psteps);
+      a.part_m = a.npix_tiles * BPIX;
+      const size_t need = (size_t)a.psplit * a.Cst * a.part_m * sizeof(float);
+      if (a.plan) { if (need > *a.plan) *a.plan = need; return 0; }
+      if (a.psplit > 1 && need <= a.ws_bytes) {
+        a.part = (float*)a.ws;
+        grid.z = a.psplit;
+        hipLaunchKernelGGL((conv_dma_kernel<BCO, BPIX, WCO, WPIX>), grid, dim3(256), 0, st, a);
+        S2P_CHECK_LAUNCH("conv_dma_kernel(split)");
+        const long long n = (long long)a.M * ((a.Cst + 7) / 8);
+        hipLaunchKernelGGL(conv_part_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, a);
+        S2P_CHECK_LAUNCH("conv_part_reduce_kernel");
+        return 0;
+      }
+      a.psplit = 1; a.part = nullptr;
+    }
+  }
+  if (a.plan) return 0;
   if (no_dma) hipLaunchKernelGGL((conv_fast_kernel<BCO, BPIX, WCO, WPIX>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((conv_dma_kernel<BCO, BPIX, WCO, WPIX>), grid, dim3(256), 0, st, a);
   S2P_CHECK_LAUNCH("conv_fast_kernel");
@@ -1150,6 +1285,9 @@ static int launch_gather(GatherArgs& a, int groups, long long x_elems, hipStream
 
 static int pack_tap(int dy, int dx, int wt) { return (wt << 16) | ((dx & 0xff) << 8) | (dy & 0xff); }
 
+// caller's scratch for K-split launches (ws may be null), or a dry run that only reports the bytes needed (plan)
+struct Scratch { void* ws; size_t bytes; size_t* plan; };
+
 // geometry of one generic problem: gathered tensor (Hi,Wi,Ci,xpitch,xg), produced tensor (Ho,Wo,Co,Cst,ypitch,yg)
 struct Geo {
   int N, Hi, Wi, Ci, xp, xg, Ho, Wo, Co, Cst, yp, yg, KH, KW, stride, pad, reflect, groups;
@@ -1160,8 +1298,9 @@ struct Geo {
 template <typename T>
 static int run_gather(const Geo& G, const void* x, const void* w, const float* bias, const void* aux,
                       const void* aux2, void* y,
-                      int act, float slope, int epi, int gact, float gslope, hipStream_t st) {
+                      int act, float slope, int epi, int gact, float gslope, hipStream_t st, const Scratch& sc) {
   GatherArgs a{};
+  a.ws = sc.ws; a.ws_bytes = sc.bytes; a.plan = sc.plan;
   a.x = x; a.w = w; a.bias = bias; a.aux = aux; a.aux2 = aux2; a.y = y;
   a.Hi = G.Hi; a.Wi = G.Wi; a.Qh = G.Ho; a.Qw = G.Wo; a.M = G.N * G.Ho * G.Wo;
   a.Cin = G.Ci; a.x_pitch = G.xp; a.x_gstride = G.xg;
@@ -1180,7 +1319,7 @@ static int run_gather(const Geo& G, const void* x, const void* w, const float* b
 template <typename T>
 static int run_scatter(const Geo& G, const void* x, const void* w, const float* bias, const void* aux,
                        const void* aux2, void* y,
-                       int act, float slope, int epi, int gact, float gslope, hipStream_t st) {
+                       int act, float slope, int epi, int gact, float gslope, hipStream_t st, const Scratch& sc) {
   const int s = G.stride;
   if constexpr (sizeof(T) == 2) {
     // all s*s phases in ONE launch of the LDS-DMA kernel (blockIdx.z = phase) when that kernel applies
@@ -1223,6 +1362,7 @@ static int run_scatter(const Geo& G, const void* x, const void* w, const float* 
           ++np;
         }
       if (ok && np > 0) {
+        if (sc.plan) return 0;
         a.nphase = np;
         const int BCO = a.Cst > 64 ? 128 : 64;
         a.nco_tiles = cdiv(a.Cst, BCO);
@@ -1237,6 +1377,7 @@ static int run_scatter(const Geo& G, const void* x, const void* w, const float* 
   for (int py = 0; py < s; ++py)
     for (int px = 0; px < s; ++px) {
       GatherArgs a{};
+      a.ws = sc.ws; a.ws_bytes = sc.bytes; a.plan = sc.plan;
       a.x = x; a.w = w; a.bias = bias; a.aux = aux; a.aux2 = aux2; a.y = y;
       a.Hi = G.Hi; a.Wi = G.Wi;
       a.Qh = (G.Ho - py + s - 1) / s; a.Qw = (G.Wo - px + s - 1) / s;
@@ -1277,15 +1418,17 @@ static int check_desc(const s2p_conv_desc* d, const char* who) {
   return 0;
 }
 
-extern "C" int s2p_conv2d_fwd(const s2p_conv_desc* d, const void* x, const void* w_fwd, const float* bias,
-                              const void* aux, void* y, int act, float slope, int epi, void* stream) {
+static int conv_fwd_impl(const s2p_conv_desc* d, const void* x, const void* w_fwd, const float* bias, const void* aux,
+                         void* y, int act, float slope, int epi, const Scratch& sc, void* stream) {
   int rc = check_desc(d, "s2p_conv2d_fwd");
   if (rc) return rc;
-  if (!x || !w_fwd || !y) S2P_FAIL(-1, "s2p_conv2d_fwd: null pointer");
-  if (epi != S2P_EPI_STORE && !aux) S2P_FAIL(-1, "s2p_conv2d_fwd: epi needs aux");
+  if (!sc.plan) {
+    if (!x || !w_fwd || !y) S2P_FAIL(-1, "s2p_conv2d_fwd: null pointer");
+    if (epi != S2P_EPI_STORE && !aux) S2P_FAIL(-1, "s2p_conv2d_fwd: epi needs aux");
+  }
   hipStream_t st = (hipStream_t)stream;
   int ce = d->dtype == S2P_F32 ? 4 : 8;
-  if (epi == S2P_EPI_STORE && s2p_thin_applicable(d)) return s2p_thin_fwd(d, x, w_fwd, bias, y, act, slope, st);
+  if (epi == S2P_EPI_STORE && s2p_thin_applicable(d)) return sc.plan ? 0 : s2p_thin_fwd(d, x, w_fwd, bias, y, act, slope, st);
   Geo G{d->N, d->H, d->W, d->Cin, d->x_pitch, d->x_gstride, d->Ho, d->Wo, d->Cout,
         /*Cst*/ d->groups == 1 ? ((d->Cout + ce - 1) / ce * ce <= d->y_pitch ? (d->Cout + ce - 1) / ce * ce : d->Cout)
                                : d->Cout,
@@ -1293,21 +1436,38 @@ extern "C" int s2p_conv2d_fwd(const s2p_conv_desc* d, const void* x, const void*
         (long long)d->Cout * d->KH * d->KW * d->Cin, d->KH * d->KW * d->Cin};
   if (d->transposed) {
     if (d->reflect) S2P_FAIL(-1, "s2p_conv2d_fwd: reflect + transposed unsupported");
-    return d->dtype == S2P_F32 ? run_scatter<float>(G, x, w_fwd, bias, aux, nullptr, y, act, slope, epi, 0, 0.f, st)
-                               : run_scatter<__bf16>(G, x, w_fwd, bias, aux, nullptr, y, act, slope, epi, 0, 0.f, st);
+    return d->dtype == S2P_F32 ? run_scatter<float>(G, x, w_fwd, bias, aux, nullptr, y, act, slope, epi, 0, 0.f, st, sc)
+                               : run_scatter<__bf16>(G, x, w_fwd, bias, aux, nullptr, y, act, slope, epi, 0, 0.f, st, sc);
   }
-  return d->dtype == S2P_F32 ? run_gather<float>(G, x, w_fwd, bias, aux, nullptr, y, act, slope, epi, 0, 0.f, st)
-                             : run_gather<__bf16>(G, x, w_fwd, bias, aux, nullptr, y, act, slope, epi, 0, 0.f, st);
+  return d->dtype == S2P_F32 ? run_gather<float>(G, x, w_fwd, bias, aux, nullptr, y, act, slope, epi, 0, 0.f, st, sc)
+                             : run_gather<__bf16>(G, x, w_fwd, bias, aux, nullptr, y, act, slope, epi, 0, 0.f, st, sc);
+}
+
+extern "C" int s2p_conv2d_fwd(const s2p_conv_desc* d, const void* x, const void* w_fwd, const float* bias,
+                              const void* aux, void* y, int act, float slope, int epi, void* stream) {
+  return conv_fwd_impl(d, x, w_fwd, bias, aux, y, act, slope, epi, Scratch{nullptr, 0, nullptr}, stream);
+}
+extern "C" int s2p_conv2d_fwd_ws(const s2p_conv_desc* d, const void* x, const void* w_fwd, const float* bias,
+                                 const void* aux, void* y, int act, float slope, int epi, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  return conv_fwd_impl(d, x, w_fwd, bias, aux, y, act, slope, epi, Scratch{workspace, workspace_bytes, nullptr}, stream);
+}
+extern "C" size_t s2p_conv2d_fwd_workspace(const s2p_conv_desc* d, int epi) {
+  size_t need = 0;
+  if (conv_fwd_impl(d, nullptr, nullptr, nullptr, nullptr, nullptr, S2P_ACT_NONE, 0.f, epi, Scratch{nullptr, 0, &need}, nullptr)) return 0;
+  return need;
 }
 
 // dgrad: gathered tensor = dy (grid Ho x Wo, channels Cout), produced tensor = dx (grid H x W, channels Cin).
 // With reflect padding the produced grid is the PADDED one, (H+2p) x (W+2p): fold it with s2p_reflect_pad_bwd.
-extern "C" int s2p_conv2d_dgrad(const s2p_conv_desc* d, const void* dy, const void* w_bwd, const void* aux,
-                                const void* aux2, void* dx, int epi, int aux_act, float slope, void* stream) {
+static int conv_dgrad_impl(const s2p_conv_desc* d, const void* dy, const void* w_bwd, const void* aux, const void* aux2,
+                           void* dx, int epi, int aux_act, float slope, const Scratch& sc, void* stream) {
   int rc = check_desc(d, "s2p_conv2d_dgrad");
   if (rc) return rc;
-  if (!dy || !w_bwd || !dx) S2P_FAIL(-1, "s2p_conv2d_dgrad: null pointer");
-  if (epi != S2P_EPI_STORE && !aux) S2P_FAIL(-1, "s2p_conv2d_dgrad: epi needs aux");
+  if (!sc.plan) {
+    if (!dy || !w_bwd || !dx) S2P_FAIL(-1, "s2p_conv2d_dgrad: null pointer");
+    if (epi != S2P_EPI_STORE && !aux) S2P_FAIL(-1, "s2p_conv2d_dgrad: epi needs aux");
+  }
   hipStream_t st = (hipStream_t)stream;
   int ce = d->dtype == S2P_F32 ? 4 : 8;
   int cout_pad = (d->Cout + ce - 1) / ce * ce;       // channels of dy actually gathered
@@ -1318,8 +1478,23 @@ extern "C" int s2p_conv2d_dgrad(const s2p_conv_desc* d, const void* dy, const vo
         d->x_pitch, d->x_gstride, d->KH, d->KW, d->stride, pad, 0, d->groups,
         (long long)d->Cin * d->KH * d->KW * cout_pad, d->KH * d->KW * cout_pad};
   if (d->transposed)   // adjoint of a scatter is a gather
-    return d->dtype == S2P_F32 ? run_gather<float>(G, dy, w_bwd, nullptr, aux, aux2, dx, S2P_ACT_NONE, 0.f, epi, aux_act, slope, st)
-                               : run_gather<__bf16>(G, dy, w_bwd, nullptr, aux, aux2, dx, S2P_ACT_NONE, 0.f, epi, aux_act, slope, st);
-  return d->dtype == S2P_F32 ? run_scatter<float>(G, dy, w_bwd, nullptr, aux, aux2, dx, S2P_ACT_NONE, 0.f, epi, aux_act, slope, st)
-                             : run_scatter<__bf16>(G, dy, w_bwd, nullptr, aux, aux2, dx, S2P_ACT_NONE, 0.f, epi, aux_act, slope, st);
+    return d->dtype == S2P_F32 ? run_gather<float>(G, dy, w_bwd, nullptr, aux, aux2, dx, S2P_ACT_NONE, 0.f, epi, aux_act, slope, st, sc)
+                               : run_gather<__bf16>(G, dy, w_bwd, nullptr, aux, aux2, dx, S2P_ACT_NONE, 0.f, epi, aux_act, slope, st, sc);
+  return d->dtype == S2P_F32 ? run_scatter<float>(G, dy, w_bwd, nullptr, aux, aux2, dx, S2P_ACT_NONE, 0.f, epi, aux_act, slope, st, sc)
+                             : run_scatter<__bf16>(G, dy, w_bwd, nullptr, aux, aux2, dx, S2P_ACT_NONE, 0.f, epi, aux_act, slope, st, sc);
+}
+
+extern "C" int s2p_conv2d_dgrad(const s2p_conv_desc* d, const void* dy, const void* w_bwd, const void* aux,
+                                const void* aux2, void* dx, int epi, int aux_act, float slope, void* stream) {
+  return conv_dgrad_impl(d, dy, w_bwd, aux, aux2, dx, epi, aux_act, slope, Scratch{nullptr, 0, nullptr}, stream);
+}
+extern "C" int s2p_conv2d_dgrad_ws(const s2p_conv_desc* d, const void* dy, const void* w_bwd, const void* aux,
+                                   const void* aux2, void* dx, int epi, int aux_act, float slope, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  return conv_dgrad_impl(d, dy, w_bwd, aux, aux2, dx, epi, aux_act, slope, Scratch{workspace, workspace_bytes, nullptr}, stream);
+}
+extern "C" size_t s2p_conv2d_dgrad_workspace(const s2p_conv_desc* d) {
+  size_t need = 0;
+  if (conv_dgrad_impl(d, nullptr, nullptr, nullptr, nullptr, nullptr, S2P_EPI_STORE, S2P_ACT_NONE, 0.f, Scratch{nullptr, 0, &need}, nullptr)) return 0;
+  return need;
 }

@@ -103,9 +103,11 @@ def conv_fwd(geom, x, w_fwd, bias, cin_pad, y_pitch=None, act=ACT_NONE, slope=0.
         y_pitch = pad_to(geom.cout * geom.groups if geom.groups > 1 else geom.cout, ce)
     y = out if out is not None else torch.empty((N, Ho, Wo, y_pitch), dtype=x.dtype, device=x.device)
     d = geom.desc(x.dtype, N, H, W, cin_pad, xp, y_pitch)
+    need = lib().s2p_conv2d_fwd_workspace(ctypes.byref(d), epi)        # > 0: small-map launch that splits K over the idle CUs
+    ws = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None
     pr = _Prof("fwd", geom, N, H, W, x.dtype)
-    check(lib().s2p_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(w_fwd), ptr(bias), ptr(aux), ptr(y), act, slope, epi,
-                               stream()), "s2p_conv2d_fwd")
+    check(lib().s2p_conv2d_fwd_ws(ctypes.byref(d), ptr(x), ptr(w_fwd), ptr(bias), ptr(aux), ptr(y), act, slope, epi,
+                                  ptr(ws), need, stream()), "s2p_conv2d_fwd")
     pr.done()
     return y
 
@@ -135,9 +137,11 @@ def conv_dgrad(geom, dy, w_bwd, x_shape, cin_pad, aux=None, epi=EPI_STORE, aux_a
     dx = torch.empty((N, H, W, xp), dtype=dy.dtype, device=dy.device)
     if xp != cin_pad * geom.groups:
         dx.zero_()
+    need = lib().s2p_conv2d_dgrad_workspace(ctypes.byref(d))
+    ws = torch.empty(need, dtype=torch.uint8, device=dy.device) if need else None
     pr = _Prof("dgrad", geom, N, H, W, dy.dtype)
-    check(lib().s2p_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(w_bwd), ptr(aux), ptr(aux2), ptr(dx), epi, aux_act, slope,
-                                 stream()), "s2p_conv2d_dgrad")
+    check(lib().s2p_conv2d_dgrad_ws(ctypes.byref(d), ptr(dy), ptr(w_bwd), ptr(aux), ptr(aux2), ptr(dx), epi, aux_act, slope,
+                                    ptr(ws), need, stream()), "s2p_conv2d_dgrad")
     pr.done()
     return dx
 

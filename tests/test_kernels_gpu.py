@@ -405,6 +405,47 @@ def test_conv_wgrad_batched_slab(hip_device, case):
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
 
 
+@pytest.mark.parametrize("case", [(256, 512, 4, 2, 7, 7, 8), (256, 256, 4, 2, 12, 12, 6), (512, 128, 2, 1, 9, 8, 5)])
+def test_conv_small_map_splitk(hip_device, case):
+    """Small maps with a long K (the PatchGAN 256->512 4x4 layers): the launch cannot fill the chip, so K is split over
+    blockIdx.z and a second kernel applies bias / activation / epilogue to the fixed-order sum
+    (s2p_conv2d_{fwd,dgrad}_ws).  Checks the plain and producer-activation-gradient epilogues against float64, that the
+    split path is the one taken, and bitwise reproducibility."""
+    cin, cout, k, p, H, W, N = case
+    dev, dtype = hip_device, torch.bfloat16
+    g = torch.Generator().manual_seed(3 + cin + k)
+    x = torch.randn(N, cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)).bfloat16().float()
+    b = torch.randn(cout, generator=g)
+    geom = ops.ConvGeom(cin, cout, k, 1, p)
+    Ho, Wo = geom.out_hw(H, W)
+    d = geom.desc(dtype, N, H, W, cin, cin, cout)
+    assert lib().s2p_conv2d_fwd_workspace(ctypes.byref(d), EPI_STORE) > 0
+    if cout >= 256:
+        assert lib().s2p_conv2d_dgrad_workspace(ctypes.byref(d)) > 0
+    xd = nhwc(x, cin, dtype, dev)
+    wf, wb = pack_fwd(w, cin, dtype, dev), pack_bwd(w, cin, cout, dtype, dev)
+    y_ref = F.conv2d(x.double(), w.double(), b.double(), padding=p)
+    y = ops.conv_fwd(geom, xd, wf, b.to(dev), cin, act=ACT_LRELU, slope=0.2)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(y, cout), F.leaky_relu(y_ref, 0.2)) < TOL[dtype]
+    assert torch.equal(y, ops.conv_fwd(geom, xd, wf, b.to(dev), cin, act=ACT_LRELU, slope=0.2))
+    # dgrad with the fused producer-activation gradient and a second incoming gradient: dx = (dgrad(dy) + g2) * relu'(a)
+    dy = torch.randn(N, cout, Ho, Wo, generator=g).bfloat16().float()
+    a_in = F.relu(torch.randn(N, cin, H, W, generator=g)).bfloat16().float()
+    g2 = torch.randn(N, cin, H, W, generator=g).bfloat16().float()
+    dyd = nhwc(dy, cout, dtype, dev)
+    dx_ref = torch.nn.grad.conv2d_input((N, cin, H, W), w.double(), dy.double(), padding=p)
+    dx = ops.conv_dgrad(geom, dyd, wb, tuple(xd.shape), cin)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(dx, cin), dx_ref) < TOL[dtype]
+    dx2 = ops.conv_dgrad(geom, dyd, wb, tuple(xd.shape), cin, aux=nhwc(a_in, cin, dtype, dev), epi=EPI_MUL_ACTGRAD,
+                         aux_act=ACT_RELU, aux2=nhwc(g2, cin, dtype, dev))
+    torch.cuda.synchronize()
+    assert rel_err(nchw(dx2, cin), (dx_ref + g2.double()) * (a_in > 0).double()) < TOL[dtype]
+    assert torch.equal(dx, ops.conv_dgrad(geom, dyd, wb, tuple(xd.shape), cin))
+
+
 @pytest.mark.parametrize("case", [
     # cin, cout, k, stride, pad, transposed, H, W, N
     (6, 64, 4, 2, 2, False, 42, 42, 8),        # PatchGAN first layer: one tile, hundreds of split units (16-segment reduce)

@@ -22,6 +22,11 @@ SHAPES = [
     ("D2 128->256 s2 @22", 128, 22, 22, 128, 256, 4, 2, 2, 0, 0, 1),
     ("D3 256->512 s1 @12", 128, 12, 12, 256, 512, 4, 1, 2, 0, 0, 1),
     ("D4 512->1 s1 @13", 128, 13, 13, 512, 1, 4, 1, 2, 0, 0, 1),
+    ("N64 D3 256->512 s1 @12", 64, 12, 12, 256, 512, 4, 1, 2, 0, 0, 1),
+    ("N64 D3 256->512 s1 @7", 64, 7, 7, 256, 512, 4, 1, 2, 0, 0, 1),
+    ("N64 D2 128->256 s2 @12", 64, 12, 12, 128, 256, 4, 2, 2, 0, 0, 1),
+    ("N64 vgg4_2 512->512 @10", 64, 10, 10, 512, 512, 3, 1, 1, 0, 0, 1),
+    ("N64 vgg5_1 512->512 @5", 64, 5, 5, 512, 512, 3, 1, 1, 0, 0, 1),
     ("vgg1_2 64->64 @84 (2N)", 128, 84, 84, 64, 64, 3, 1, 1, 0, 0, 1),
     ("vgg2_2 128->128 @42", 128, 42, 42, 128, 128, 3, 1, 1, 0, 0, 1),
     ("vgg3_2 256->256 @21", 128, 21, 21, 256, 256, 3, 1, 1, 0, 0, 1),
@@ -30,13 +35,18 @@ SHAPES = [
 ]
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
 def timeit(fn, n=20):
+    """us per call, replayed from a hipGraph of n back-to-back calls (no host launch cost in the number)."""
     for _ in range(3): fn()
     torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n): fn()
+    g.replay(); torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(n): fn()
+    for _ in range(5): g.replay()
     e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e3   # us
+    return e0.elapsed_time(e1) / (5 * n) * 1e3   # us
 print("%-32s %10s %10s %10s   (us | TFLOP/s)" % ("shape", "fwd", "dgrad", "wgrad"))
 tot = [0, 0, 0]
 for (name, N, H, W, cin, cout, k, s, p, tr, refl, G) in SHAPES:
