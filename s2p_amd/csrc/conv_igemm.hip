@@ -1239,7 +1239,7 @@ static int launch_fast(GatherArgs& a, int groups, hipStream_t st) {
   // over the idle CUs instead.
   static const int no_split = s2p_env_set("S2P_NO_CONV_SPLITK");
   if (!no_dma && !no_split && groups == 1 && a.nphase == 0 && a.ostride == 1 && a.oy0 == 0 && a.ox0 == 0 && a.Qh == a.Ho &&
-      a.Qw == a.Wo && a.epi != S2P_EPI_ADD && (a.plan || a.ws)) {
+      a.Qw == a.Wo && (a.plan || a.ws)) {
     const int nk = a.Ktot / 64;
     const int S = conv_split_plan((int)grid.x, nk);
     if (S > 1) {

@@ -220,11 +220,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
   const int tiles = a.na_tiles * a.nb_tiles;
   int g, split, tile;
   {
+    // the (unit, tile) items in unit-major order are cut into 8 contiguous runs, one per XCD: whole units when the unit
+    // count is a multiple of 8, otherwise a unit's tiles are shared by at most two XCDs
     const int L = blockIdx.x, xcd = L & 7, k = L >> 3;
-    const int j = k / tiles;
-    tile = k - j * tiles;
-    const int u = j * 8 + xcd;
-    if (u >= a.groups * a.splitk) return;               // whole workgroup: idle filler of the last unit row
+    const int total = tiles * a.groups * a.splitk, per = (total + 7) >> 3;
+    const int item = xcd * per + k;
+    if (item >= total) return;                          // whole workgroup: filler of the last run
+    const int u = item / tiles;
+    tile = item - u * tiles;
     g = u / a.splitk; split = u - g * a.splitk;
   }
   const int a_tile = tile % a.na_tiles, b_tile = tile / a.na_tiles;
@@ -474,12 +477,13 @@ __global__ __launch_bounds__(64 * NSEG) void wgrad_part_reduce_kernel(const Wgra
   }
 }
 
-// split count of the LDS-DMA kernels: (groups * splits) a multiple of 8 (one unit per XCD per round), enough workgroups
-// to fill the chip
+// split count of the LDS-DMA kernels: enough (unit, tile) workgroups to fill the chip; every extra unit costs one more
+// partial tile set to store and to reduce
 static void wgrad_dma_splits(WgradArgs& a, int groups, int target) {
   const int tiles = a.na_tiles * a.nb_tiles;
   const int total = cdiv(a.M, 32);
-  int U = 8 * (cdiv(target, tiles * 8) > 1 ? cdiv(target, tiles * 8) : 1);
+  int U = cdiv(target, tiles);
+  if (U < 1) U = 1;
   int sk = cdiv(U, groups);
   if (sk > total) sk = total;
   if (sk < 1) sk = 1;
@@ -516,7 +520,7 @@ static bool wgrad_dma_plan(const s2p_conv_desc* d, int cin_real, int cout_real, 
   dense = a.a_pitch <= 1024 && a.b_pitch <= 1024;
   if (!wgrad_dma_ok(d) || s2p_env_set("S2P_NO_LDS_DMA")) return false;
   if (!dense && s2p_env_set("S2P_NO_WGRAD_WIDE_DMA")) return false;
-  wgrad_dma_splits(a, d->groups, dense ? s2p_env_int("S2P_WGRAD_BLOCKS", 384) : 384);
+  wgrad_dma_splits(a, d->groups, dense ? s2p_env_int("S2P_WGRAD_BLOCKS", 512) : 512);
   a.part_rows = a.na_tiles * 128; a.part_cols = a.nb_tiles * 128;
   return true;
 }
@@ -588,7 +592,7 @@ extern "C" int s2p_conv2d_wgrad_ws(const s2p_conv_desc* d, const void* x, const 
         a.part_b = a.part + (size_t)units * a.part_rows * a.part_cols;
       }
       const int tiles = a.na_tiles * a.nb_tiles;
-      dim3 grid1(8 * tiles * cdiv(units, 8));
+      dim3 grid1(8 * cdiv((long long)tiles * units, 8));
       if (dense) hipLaunchKernelGGL(wgrad_dma_kernel<32>, grid1, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((wgrad_dma_kernel<32, 2, false>), grid1, dim3(256), 0, st, a);
       S2P_CHECK_LAUNCH("wgrad_dma_kernel");
@@ -597,7 +601,8 @@ extern "C" int s2p_conv2d_wgrad_ws(const s2p_conv_desc* d, const void* x, const 
         const int n_bias = a.db ? a.groups * a.Ca_real : 0;
         if (n_out >= (1ll << 31)) S2P_FAIL(-2, "s2p_conv2d_wgrad: dW too large");
         const int nblk = cdiv(n_out + n_bias, 64);
-        if (a.splitk > 16) hipLaunchKernelGGL(wgrad_part_reduce_kernel<16>, dim3(nblk), dim3(1024), 0, st, a, (int)n_out, n_bias);
+        if (a.splitk > 128) hipLaunchKernelGGL(wgrad_part_reduce_kernel<16>, dim3(nblk), dim3(1024), 0, st, a, (int)n_out, n_bias);
+        else if (a.splitk > 32) hipLaunchKernelGGL(wgrad_part_reduce_kernel<4>, dim3(nblk), dim3(256), 0, st, a, (int)n_out, n_bias);
         else hipLaunchKernelGGL(wgrad_part_reduce_kernel<1>, dim3(nblk), dim3(64), 0, st, a, (int)n_out, n_bias);
         S2P_CHECK_LAUNCH("wgrad_part_reduce_kernel");
       }

@@ -409,7 +409,7 @@ def test_conv_wgrad_batched_slab(hip_device, case):
 def test_conv_small_map_splitk(hip_device, case):
     """Small maps with a long K (the PatchGAN 256->512 4x4 layers): the launch cannot fill the chip, so K is split over
     blockIdx.z and a second kernel applies bias / activation / epilogue to the fixed-order sum
-    (s2p_conv2d_{fwd,dgrad}_ws).  Checks the plain and producer-activation-gradient epilogues against float64, that the
+    (s2p_conv2d_{fwd,dgrad}_ws).  Checks the plain, residual-add and producer-activation-gradient epilogues against float64, that the
     split path is the one taken, and bitwise reproducibility."""
     cin, cout, k, p, H, W, N = case
     dev, dtype = hip_device, torch.bfloat16
@@ -443,6 +443,9 @@ def test_conv_small_map_splitk(hip_device, case):
                          aux_act=ACT_RELU, aux2=nhwc(g2, cin, dtype, dev))
     torch.cuda.synchronize()
     assert rel_err(nchw(dx2, cin), (dx_ref + g2.double()) * (a_in > 0).double()) < TOL[dtype]
+    dx3 = ops.conv_dgrad(geom, dyd, wb, tuple(xd.shape), cin, aux=nhwc(g2, cin, dtype, dev), epi=EPI_ADD)      # dx = dgrad(dy) + g2
+    torch.cuda.synchronize()
+    assert rel_err(nchw(dx3, cin), dx_ref + g2.double()) < TOL[dtype]
     assert torch.equal(dx, ops.conv_dgrad(geom, dyd, wb, tuple(xd.shape), cin))
 
 
