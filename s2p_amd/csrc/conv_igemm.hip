@@ -698,49 +698,69 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const GatherArgs a) {
 // (pixel, 8-channel chunk), pixels fastest: the partial reads are coalesced, the 16-B stores land in L2.
 __global__ __launch_bounds__(256) void conv_part_reduce_kernel(const GatherArgs a) {
   typedef __bf16 T;
+  // one thread per (4 consecutive pixels, 8-channel chunk), pixel groups fastest: 16-B partial loads, coalesced
+  const int m4n = a.part_m >> 2;                         // part_m is a multiple of 128
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   const int nch = (a.Cst + 7) / 8;
-  if (idx >= (long long)a.M * nch) return;
-  const int ch = (int)(idx / a.M), m = (int)(idx - (long long)ch * a.M);
+  if (idx >= (long long)m4n * nch) return;
+  const int ch = (int)(idx / m4n), m0 = (int)(idx - (long long)ch * m4n) * 4;
+  if (m0 >= a.M) return;
   const int co0 = ch * 8;
-  float v[8];
+  f32x4 v[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = (a.bias && co0 + e < a.Cout) ? a.bias[co0 + e] : 0.f;
+  for (int e = 0; e < 8; ++e) {
+    const float bv = (a.bias && co0 + e < a.Cout) ? a.bias[co0 + e] : 0.f;
+    v[e] = (f32x4){bv, bv, bv, bv};
+  }
   const size_t zs = (size_t)a.Cst * a.part_m;
   for (int z = 0; z < a.psplit; ++z) {
-    const float* P = a.part + z * zs + (size_t)co0 * a.part_m + m;
+    const float* P = a.part + z * zs + (size_t)co0 * a.part_m + m0;
 #pragma unroll
     for (int e = 0; e < 8; ++e)
-      if (co0 + e < a.Cst) v[e] += P[(size_t)e * a.part_m];
+      if (co0 + e < a.Cst) v[e] += *(const f32x4*)(P + (size_t)e * a.part_m);
   }
   const float ns = a.act == S2P_ACT_RELU ? 0.f : (a.act == S2P_ACT_LRELU ? a.slope : 1.f);
   const bool act_generic = (a.act == S2P_ACT_TANH || a.act == S2P_ACT_SWISH);
-  Chunk<T> c; c.raw = (u32x4){0u, 0u, 0u, 0u};
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float t = v[e];
-    const float w = act_generic ? (a.act == S2P_ACT_TANH ? tanhf(t) : t / (1.f + expf(-t))) : (t > 0.f ? t : t * ns);
-    c.set(e, w);                                       // rounded to bf16 here, as the fused epilogue does before epi
-  }
-  const size_t go = (size_t)m * a.y_pitch + co0;        // same grid, stride 1: output pixel index == GEMM pixel index
   const bool full = co0 + 8 <= a.Cst;
+  const bool epi_add = a.epi == S2P_EPI_ADD;
+  const bool g_tanh = a.gact == S2P_ACT_TANH;
+  const float gneg = a.gact == S2P_ACT_RELU ? 0.f : (a.gact == S2P_ACT_LRELU ? a.gslope : 1.f);
   T* y = (T*)a.y;
-  if (a.epi != S2P_EPI_STORE) {
-    const T* aux = (const T*)a.aux; const T* aux2 = (const T*)a.aux2;
-    const bool epi_add = a.epi == S2P_EPI_ADD;
-    const bool g_tanh = a.gact == S2P_ACT_TANH;
-    const float gneg = a.gact == S2P_ACT_RELU ? 0.f : (a.gact == S2P_ACT_LRELU ? a.gslope : 1.f);
+  const T* aux = (const T*)a.aux; const T* aux2 = (const T*)a.aux2;
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
-      if (co0 + e < a.Cst) {
-        const float xv = to_f32(aux[go + e]);
-        const float x2 = aux2 ? to_f32(aux2[go + e]) : 0.f;
-        const float f = g_tanh ? 1.f - xv * xv : (xv > 0.f ? 1.f : gneg);
-        c.set(e, epi_add ? c.get(e) + xv : (c.get(e) + x2) * f);
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + i;
+    if (m >= a.M) break;
+    Chunk<T> c; c.raw = (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float t = v[e][i];
+      const float w = act_generic ? (a.act == S2P_ACT_TANH ? tanhf(t) : t / (1.f + expf(-t))) : (t > 0.f ? t : t * ns);
+      c.set(e, w);                                       // rounded to bf16 here, as the fused epilogue does before epi
+    }
+    const size_t go = (size_t)m * a.y_pitch + co0;        // same grid, stride 1: output pixel index == GEMM pixel index
+    if (a.epi != S2P_EPI_STORE) {
+      Chunk<T> x, x2;
+      x.raw = (u32x4){0u, 0u, 0u, 0u}; x2.raw = (u32x4){0u, 0u, 0u, 0u};
+      if (full) {
+        x.raw = *(const u32x4*)(aux + go);
+        if (aux2) x2.raw = *(const u32x4*)(aux2 + go);
+      } else {
+        for (int e = 0; e < 8; ++e) if (co0 + e < a.Cst) {
+          x.set(e, to_f32(aux[go + e]));
+          if (aux2) x2.set(e, to_f32(aux2[go + e]));
+        }
       }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xv = x.get(e);
+        const float f = g_tanh ? 1.f - xv * xv : (xv > 0.f ? 1.f : gneg);
+        c.set(e, epi_add ? c.get(e) + xv : (c.get(e) + x2.get(e)) * f);
+      }
+    }
+    if (full) *(u32x4*)(y + go) = c.raw;
+    else for (int e = 0; e < 8; ++e) if (co0 + e < a.Cst) y[go + e] = from_f32<T>(c.get(e));
   }
-  if (full) *(u32x4*)(y + go) = c.raw;
-  else for (int e = 0; e < 8; ++e) if (co0 + e < a.Cst) y[go + e] = from_f32<T>(c.get(e));
 }
 
 // K-split plan of a single-phase bf16 launch (1 = no split): only launches of <= 160 workgroups, >= 16 K steps per slice
@@ -1252,7 +1272,7 @@ static int launch_fast(GatherArgs& a, int groups, hipStream_t st) {
         grid.z = a.psplit;
         hipLaunchKernelGGL((conv_dma_kernel<BCO, BPIX, WCO, WPIX>), grid, dim3(256), 0, st, a);
         S2P_CHECK_LAUNCH("conv_dma_kernel(split)");
-        const long long n = (long long)a.M * ((a.Cst + 7) / 8);
+        const long long n = (long long)(a.part_m / 4) * ((a.Cst + 7) / 8);
         hipLaunchKernelGGL(conv_part_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, a);
         S2P_CHECK_LAUNCH("conv_part_reduce_kernel");
         return 0;

@@ -363,8 +363,7 @@ __global__ __launch_bounds__(1024) void in_fused_fwd_kernel(const NormArgs a) {
     rstd[e] = 1.f / sqrtf(cst[1][cc * CE + e] * inv + a.eps);
     gs[e] = cst[2][cc * CE + e]; bs[e] = cst[3][cc * CE + e];
   }
-  const float ns = a.act == S2P_ACT_RELU ? 0.f : (a.act == S2P_ACT_LRELU ? a.slope : 1.f);
-  const bool act_generic = a.act == S2P_ACT_TANH || a.act == S2P_ACT_SWISH;
+  const float ns = a.act == S2P_ACT_RELU ? 0.f : (a.act == S2P_ACT_LRELU ? a.slope : 1.f);   // none / relu / lrelu only (host)
   T* yb = (T*)a.y + img * a.y_pitch + c0;
 #pragma unroll
   for (int k = 0; k < MAXP; ++k) {
@@ -377,7 +376,7 @@ __global__ __launch_bounds__(1024) void in_fused_fwd_kernel(const NormArgs a) {
       float bb = bs[e] + (gbb ? bv[k].get(e) : 0.f);
       float xh;
       float yv = mat_value(xv[k].get(e), mean[e], rstd[e], gg, bb, xh);
-      o0.set(e, act_generic ? act_fwd(yv, a.act, a.slope) : (yv > 0.f ? yv : yv * ns));
+      o0.set(e, yv > 0.f ? yv : yv * ns);
     }
     *(u32x4*)(yb + (size_t)p * a.y_pitch) = o0.raw;
   }
@@ -606,7 +605,8 @@ extern "C" int s2p_in_norm_fwd(int dtype, const void* x, int N, int HW, int C, i
   int rc = norm_check("s2p_in_norm_fwd", dtype, C, pitch, gb_pitch, y_pitch); if (rc) return rc;
   if (!x || !y || !stats || N <= 0 || HW <= 0) S2P_FAIL(-1, "s2p_in_norm_fwd: null pointer / empty problem");
   const int maxhw = dtype == S2P_F32 ? 256 : 512;
-  if (HW > maxhw || s2p_env_set("S2P_NO_FUSED_NORM")) {
+  const bool simple_act = act == S2P_ACT_NONE || act == S2P_ACT_RELU || act == S2P_ACT_LRELU;   // tanh / swish: two-kernel path
+  if (HW > maxhw || !simple_act || s2p_env_set("S2P_NO_FUSED_NORM")) {
     rc = s2p_in_stats(dtype, x, N, HW, C, pitch, eps, stats, stream); if (rc) return rc;
     return s2p_in_apply_fwd(dtype, x, N, HW, C, pitch, stats, gb_img, gb_pitch, gb_st, gb_st_pitch, act, slope, eps, y, y_pitch, stream);
   }
