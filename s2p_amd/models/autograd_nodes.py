@@ -69,21 +69,10 @@ def nhwc_to_nchw_apply(x, C):
 
 
 # ---------------------------------------------------------------------------------------------------------
-def _build_d_input(model, fake_nhwc, prev_image, real_image):
-    """cat([prev;fake] , [prev;real]) along batch, channels 0..2 = prev_image, 3..5 = image, pitch 8."""
-    dt = model.netD.compute_dtype
-    N, _, H, W = prev_image.shape
-    x = torch.empty((2 * N, H, W, 8), dtype=dt, device=prev_image.device)
-    ops.nchw_to_nhwc(prev_image, dt, 8, out=x[:N], c_off=0, zero_pad=True)
-    ops.nchw_to_nhwc(prev_image, dt, 8, out=x[N:], c_off=0, zero_pad=True)
-    ops.copy_channels(fake_nhwc, 0, x, 3, 3, src_rows=N)
-    ops.nchw_to_nhwc(real_image, dt, 8, out=x[N:], c_off=3, zero_pad=False)
-    return x
-
-
 def _build_d_half(model, prev_image, image_nchw=None, image_nhwc=None):
-    """One half of the D batch: cat(prev_image, image) on channels (0..2 | 3..5), pitch 8; image given as fp32 NCHW (real)
-    or as the generator's NHWC output (fake)."""
+    """One half of the D batch (the reference's cat([fake; real]) along the batch is run as two passes of N):
+    cat(prev_image, image) on channels (0..2 | 3..5), pitch 8; image given as fp32 NCHW (real) or as the generator's
+    NHWC output (fake)."""
     dt = model.netD.compute_dtype
     N, _, H, W = prev_image.shape
     x = torch.empty((N, H, W, 8), dtype=dt, device=prev_image.device)
@@ -116,6 +105,45 @@ def vgg_real_prefetch(model, real_image, dt, ce):
     return dict(real_nhwc=real_nhwc, taps=taps, acts=acts, stream=vs)
 
 
+OVERLAP_DREAL = True    # the real half of the discriminator batch on a side stream (G step: under the generator forward)
+DREAL_EARLY_BWD = True  # D step: its backward too, ahead of the fake half (only when the losses' upstream gradients are 1)
+DREAL_REUSE = True      # D step: take netD(prev, real) from the G step of the same train step instead of recomputing it
+
+
+def _dreal_key(model, prev_image, real_image):
+    """What D(prev, real) depends on: the two input tensors (identity + in-place version) and netD's packed weights."""
+    return (id(prev_image), prev_image._version, prev_image.data_ptr(), id(real_image), real_image._version,
+            real_image.data_ptr(), getattr(model.netD.store, "version", 0))
+
+
+def _record_ctx(dctx, stream):
+    for x, saved in dctx:
+        x.record_stream(stream)
+        for tup in saved:
+            for t in tup:
+                if t is not None:
+                    t.record_stream(stream)
+
+
+def dreal_pass(model, prev_image, real_image, on_side):
+    """Discriminator forward on (prev, real) -- the half of the D batch that depends on nothing either step computes.
+    The G step needs its features (feature matching), the D step its activations (weight gradients): netD's weights do
+    not change between the two, so the pass is done ONCE per train step, here, and the D step picks it up from
+    model._dreal_cache (_DStepNode).  on_side: on the `_dreal_side` stream (the caller joins `stream` before using it)."""
+    main = torch.cuda.current_stream()
+    side = _side(model, "_dreal_side") if on_side else main
+    if on_side:
+        side.wait_stream(main)
+        prev_image.record_stream(side); real_image.record_stream(side)
+    with torch.cuda.stream(side):
+        xr = _build_d_half(model, prev_image, image_nchw=real_image)
+        # (no nested fork: HIP's stream capture crashed in hipStreamEndCapture with a side stream forked from a side stream)
+        res, dctx = model.netD.fwd_nhwc(xr, lane=None if on_side else 0)
+    if on_side:
+        _record_ctx(dctx, main)
+    return dict(res=res, dctx=dctx, stream=side if on_side else None, key=_dreal_key(model, prev_image, real_image))
+
+
 def _hinge_seed(logits, mode_lo, mode_hi, N, num_D, loss_lo, loss_hi):
     """logits: NHWC [2N,h,w,ce] (1 real channel).  Applies hinge mode_lo to the first N samples and mode_hi to the
     last N (if not None); returns the gradient in the layout of `logits` ([N,...] only when mode_hi is None)."""
@@ -135,13 +163,15 @@ class _GLossNode(torch.autograd.Function):
     """G-step losses: hinge GAN + feature matching (through netD, frozen) + VGG perceptual + pixel L1."""
 
     @staticmethod
-    def forward(ctx, fake, model, prev_image, real_image, pre):
+    def forward(ctx, fake, model, prev_image, real_image, pre, pre_d):
         opt = model.opt
         N, H, W, ce = fake.shape
         dt = fake.dtype
         main = torch.cuda.current_stream()
         if pre is not None:
             main.wait_stream(pre["stream"])     # VGG(real) prefetch re-joins here (it ran under the generator forward)
+        if pre_d is not None and pre_d["stream"] is not None:
+            main.wait_stream(pre_d["stream"])   # ... and so does the D(prev, real) pass
         if model.before_netD is not None:
             # data-parallel hook (a StepGraph cut point): D's weight update of the previous step must have landed before
             # netD is used below.  It sits here, ahead of the stream fork, because a graph segment cannot end while a
@@ -175,19 +205,28 @@ class _GLossNode(torch.autograd.Function):
                     tg = torch.empty_like(t)
                     ops.l1_loss(t, tr, opt.lambda_vgg * wk / t.numel(), losses[2:3], tg)
                     tap_grads.append(tg)
-        x = _build_d_input(model, fake, prev_image, real_image)
-        res, dctx = model.netD.fwd_nhwc(x)
+        # The discriminator sees the two halves of its batch as two passes of N (InstanceNorm is per-sample, so the
+        # halves are independent): (prev, real) may already have been done under the generator forward (dreal_pass in
+        # compute_generator_loss); otherwise it goes on its side stream now, next to the (prev, fake) pass.
+        dreal = pre_d
+        if dreal is None:
+            dreal = dreal_pass(model, prev_image, real_image, OVERLAP_DREAL and not ops.SERIALIZE)
+        xf = _build_d_half(model, prev_image, image_nhwc=fake)
+        res, dctx = model.netD.fwd_nhwc(xf)
+        if pre_d is None and dreal["stream"] is not None:
+            main.wait_stream(dreal["stream"])
+        res_r = dreal["res"]
+        model._dreal_cache = dreal                 # the D step of this train step reuses it (same inputs, same netD weights)
         num_D = len(res)
         grads = []
-        for feats in res:
+        for feats, feats_r in zip(res, res_r):
             g = [None] * len(feats)
             g[-1] = _hinge_seed(feats[-1], 2, None, N, num_D, losses[0:1], None)
             if not opt.no_ganFeat_loss:
                 for j in range(len(feats) - 1):
                     f = feats[j]
-                    gf = torch.empty_like(f[:N])             # gradient of the fake half only (real half: detached)
-                    half = f[:N].numel()
-                    ops.l1_loss(f[:N], f[N:], opt.lambda_feat / num_D / half, losses[1:2], gf)
+                    gf = torch.empty_like(f)                 # gradient of the fake pass only (real features: detached)
+                    ops.l1_loss(f, feats_r[j], opt.lambda_feat / num_D / f.numel(), losses[1:2], gf)
                     g[j] = gf
             grads.append(g)
         if vgg_on_side:
@@ -195,6 +234,7 @@ class _GLossNode(torch.autograd.Function):
         ctx.vgg_on_side = vgg_on_side
         ctx.model, ctx.dctx, ctx.grads, ctx.vctx, ctx.tap_grads, ctx.d_fake, ctx.N = \
             model, dctx, grads, vctx, tap_grads, d_fake, N
+        ctx.dctx_r = dreal["dctx"]                                                 # (parity tests' branch masks)
         ctx.vctx_real, ctx.real_nhwc, ctx.fake = vctx_real, real_nhwc, fake      # (kept for the parity tests' branch masks)
         # one zero-dim output per loss term (not one [4] tensor indexed by the caller): the trainer's
         # sum(losses.values()).mean().backward() then costs no select-backward zero-fill / copy / accumulate kernels
@@ -226,30 +266,27 @@ class _GLossNode(torch.autograd.Function):
                 dv = model.vgg.bwd_nhwc(ctx.vctx, ctx.tap_grads, N)
             if ctx.vgg_on_side:
                 dv.record_stream(main)
-        dx = model.netD.bwd_nhwc(ctx.dctx, ctx.grads, need_wgrad=False, need_dx=True, n_keep=N)   # fake half only
+        dx = model.netD.bwd_nhwc(ctx.dctx, ctx.grads, need_wgrad=False, need_dx=True)
         ops.copy_channels(dx, 3, d_fake, 0, 3, accumulate=True, src_rows=N)
         if dv is not None:
             if ctx.vgg_on_side:
                 main.wait_stream(vs)
             ops.add(d_fake, dv, out=d_fake)
-        ctx.dctx = ctx.grads = ctx.vctx = ctx.tap_grads = ctx.vctx_real = ctx.real_nhwc = ctx.fake = None
-        return d_fake, None, None, None, None
+        ctx.dctx = ctx.dctx_r = ctx.grads = ctx.vctx = ctx.tap_grads = ctx.vctx_real = ctx.real_nhwc = ctx.fake = None
+        return d_fake, None, None, None, None, None
 
 
-def g_losses_apply(model, fake_nhwc, prev_image, real_image, pre=None):
-    return _GLossNode.apply(fake_nhwc, model, prev_image, real_image, pre)
-
-
-OVERLAP_DREAL = True    # D step: the real half of the discriminator pass on a side stream, under the generator forward
-DREAL_EARLY_BWD = True  # ... including its backward (only when the losses' upstream gradients are known to be 1)
+def g_losses_apply(model, fake_nhwc, prev_image, real_image, pre=None, pre_d=None):
+    return _GLossNode.apply(fake_nhwc, model, prev_image, real_image, pre, pre_d)
 
 
 class _DStepNode(torch.autograd.Function):
     """The whole D step as one node: fake = G(prev, state) without gradient, hinge on D(prev, fake) and D(prev, real);
     weight gradients go to netD's flat buffer.  The two halves of the D batch are independent (InstanceNorm is
-    per-sample), and the real half depends on nothing the step computes: it runs on a side stream while the generator
-    forward occupies the main stream -- forward AND, when the losses' upstream gradients are known to be 1 (the
-    trainer), its backward too.  The fake half follows on the main stream."""
+    per-sample), and the real half depends on nothing the step computes: its forward is normally the one the G step of the
+    same train step already did (model._dreal_cache: same inputs, same netD weights -- the reference recomputes it);
+    its backward runs on a side stream while the generator forward occupies the main stream when the losses' upstream
+    gradients are known to be 1 (the trainer).  The fake half follows on the main stream."""
 
     @staticmethod
     def forward(ctx, anchor, model, prev_image, state, real_image, fake_given):
@@ -272,14 +309,28 @@ class _DStepNode(torch.autograd.Function):
                 grads.append(g)
             return dctx, grads
 
+        # the (prev, real) forward of this train step's G step, if it is still valid (same inputs, netD not updated since)
+        cache = getattr(model, "_dreal_cache", None)
+        model._dreal_cache = None
+        if cache is not None and (not DREAL_REUSE or cache["key"] != _dreal_key(model, prev_image, real_image)):
+            cache = None
         if use_side:
             side.wait_stream(main)
             for t in (prev_image, real_image, losses):
                 t.record_stream(side)
         with torch.cuda.stream(side):
-            xr = _build_d_half(model, prev_image, image_nchw=real_image)
-            # (no nested fork: HIP's stream capture crashed in hipStreamEndCapture with a side stream forked from a side stream)
-            dctx_r, grads_r = half(xr, 1, losses[1:2], None if use_side else 0)
+            if cache is not None:
+                dctx_r = cache["dctx"]
+                grads_r = []
+                for feats in cache["res"]:
+                    g = [None] * len(feats)
+                    g[-1] = _hinge_seed(feats[-1], 1, None, N, num_D, losses[1:2], None)
+                    grads_r.append(g)
+                cache = None
+            else:
+                xr = _build_d_half(model, prev_image, image_nchw=real_image)
+                # (no nested fork: HIP's stream capture crashed in hipStreamEndCapture with a side stream forked from a side stream)
+                dctx_r, grads_r = half(xr, 1, losses[1:2], None if use_side else 0)
             if unit and DREAL_EARLY_BWD:               # upstream gradient is 1: the real half's backward can go now
                 netD.bwd_nhwc(dctx_r, grads_r, need_wgrad=True, need_dx=False)
                 dctx_r = grads_r = None

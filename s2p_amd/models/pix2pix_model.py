@@ -125,12 +125,21 @@ class Pix2PixModel(nn.Module):
 
     # ---- forward ---------------------------------------------------------------------------------------------
     def preprocess_input(self, data):
+        """Device fp32 copies of the batch.  The G step and the D step of one iteration are handed the same batch: the
+        copies are made once (keyed on the source tensors' identity and in-place version), which also lets the D step
+        recognise the inputs of the G step's netD(prev, real) pass (autograd_nodes.dreal_pass)."""
         dev = self.device
-        prev = data["prev_image"].to(dev, dtype=torch.float32, non_blocking=True).contiguous()
-        state = data["state"].to(dev, dtype=torch.float32, non_blocking=True).contiguous()
-        real = data.get("image")
+        src = (data["prev_image"], data["state"], data.get("image"))
+        key = tuple((id(t), t._version, t.data_ptr()) if t is not None else None for t in src)
+        hit = getattr(self, "_pp_cache", None)
+        if hit is not None and hit[0] == key and all(a is b for a, b in zip(hit[1], src)):
+            return hit[2]
+        prev = src[0].to(dev, dtype=torch.float32, non_blocking=True).contiguous()
+        state = src[1].to(dev, dtype=torch.float32, non_blocking=True).contiguous()
+        real = src[2]
         if real is not None:
             real = real.to(dev, dtype=torch.float32, non_blocking=True).contiguous()
+        self._pp_cache = (key, src, (prev, state, real))
         return prev, state, real
 
     def forward(self, data, mode):
@@ -151,8 +160,13 @@ class Pix2PixModel(nn.Module):
             # VGG features of the real image: on the VGG side stream, under the generator forward below
             from .._lib import chunk_elems
             pre = vgg_real_prefetch(self, real, self.compute_dtype, chunk_elems(self.compute_dtype))
+        pre_d = None
+        if autograd_nodes.OVERLAP_DREAL and not ops_mod.SERIALIZE and self.before_netD is None:
+            # D(prev, real): on its side stream, under the generator forward (with data parallelism netD's weight update of
+            # the previous step may still be in flight here: the pass then runs inside the loss node, after the wait)
+            pre_d = autograd_nodes.dreal_pass(self, prev, real, True)
         fake = generator_apply(self.netG, prev, state)                 # NHWC compute dtype, autograd node
-        L = g_losses_apply(self, fake, prev, real, pre)
+        L = g_losses_apply(self, fake, prev, real, pre, pre_d)
         G_losses = {"GAN": L[0]}
         if not self.opt.no_ganFeat_loss:
             G_losses["GAN_Feat"] = L[1]

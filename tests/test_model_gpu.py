@@ -117,18 +117,19 @@ def generator_masks(net, c):
     return m
 
 
-def discriminator_masks(netD, dctx, N, with_feat_l1):
+def discriminator_masks(netD, dctx_f, dctx_r, with_feat_l1):
+    """The product runs D on (prev, fake) and (prev, real) as two passes of N (the real one under the generator forward);
+    the oracle runs cat([fake; real]): masks are concatenated on the batch."""
     m = {}
-    for k, (d, (_, saved)) in enumerate(zip(netD.subnets(), dctx)):
+    for k, (d, (_, sf), (_, sr)) in enumerate(zip(netD.subnets(), dctx_f, dctx_r)):
         nl = d.n_layers
         for n in range(nl):
-            f = _nchw(saved[n][3], d.chans[n])
-            m[f"D{k}.model{n}"] = f > 0
+            ff, fr = _nchw(sf[n][3], d.chans[n]), _nchw(sr[n][3], d.chans[n])
+            m[f"D{k}.model{n}"] = torch.cat([ff, fr], 0) > 0
             if with_feat_l1:
-                m[f"l1.feat{k}.{n}"] = torch.sign(f[:N] - f[N:])
-        logit = _nchw(saved[nl][3], 1)
-        m[f"hinge.fake{k}"] = (1.0 + logit[:N]) > 0
-        m[f"hinge.real{k}"] = (1.0 - logit[N:]) > 0
+                m[f"l1.feat{k}.{n}"] = torch.sign(ff - fr)
+        m[f"hinge.fake{k}"] = (1.0 + _nchw(sf[nl][3], 1)) > 0
+        m[f"hinge.real{k}"] = (1.0 - _nchw(sr[nl][3], 1)) > 0
     return m
 
 
@@ -280,7 +281,7 @@ def test_train_step_losses_and_grads(hip_device, tmp_path, precision, ltol, gtol
     g_losses, fake = model(data, mode="generator")
     lnode, gnode = g_losses["GAN"].grad_fn, fake.grad_fn
     masks = generator_masks(model.netG, gnode.c)
-    masks.update(discriminator_masks(model.netD, lnode.dctx, N, with_feat_l1=True))
+    masks.update(discriminator_masks(model.netD, lnode.dctx, lnode.dctx_r, with_feat_l1=True))
     masks.update(vgg_masks(lnode, N))
     sum(g_losses.values()).mean().backward()
     torch.cuda.synchronize()
@@ -323,7 +324,7 @@ def test_loss_weights_reach_the_gradients(hip_device, tmp_path):
     g_losses, fake = model(data, mode="generator")
     lnode, gnode = g_losses["GAN"].grad_fn, fake.grad_fn
     masks = generator_masks(model.netG, gnode.c)
-    masks.update(discriminator_masks(model.netD, lnode.dctx, 2, with_feat_l1=True))
+    masks.update(discriminator_masks(model.netD, lnode.dctx, lnode.dctx_r, with_feat_l1=True))
     masks.update(vgg_masks(lnode, 2))
     sum(wts[k] * v for k, v in g_losses.items()).backward()
     torch.cuda.synchronize()
@@ -343,6 +344,50 @@ def test_loss_weights_reach_the_gradients(hip_device, tmp_path):
     D64 = O.discriminator_losses(None, pd64, prev.double(), state.double(), real.double(), spec, masks=dmasks, fake=fake_hip)
     (3.0 * D64["D_Fake"] + 0.25 * D64["D_real"]).backward()
     check_grads(grad_errors(dict(model.netD.named_parameters()), pd64), 1e-4, "weighted D losses")
+
+
+def test_dstep_reuses_the_gstep_real_pass(hip_device, tmp_path):
+    """netD(prev, real) is computed once per train step: the G step's pass (feature matching) is handed to the D step
+    through model._dreal_cache (same inputs, netD not updated in between -- the reference recomputes it).  The D gradients
+    must be bit-identical to a D step that recomputes the pass, and a changed input or a netD update must invalidate it."""
+    opt, model, spec, pg, pd, pv = build("bf16", tmp_path)
+    prev, state, real = make_inputs(2, 84, 84, 17, seed=5)
+    data = dict(prev_image=prev.cuda(), state=state.cuda(), image=real.cuda())
+
+    def d_grads(after_g_step):
+        model._dreal_cache = None
+        if after_g_step:
+            with torch.no_grad():
+                model(data, mode="generator")
+            assert model._dreal_cache is not None
+        model.netD.store.zero_grad()
+        d_losses = model(data, mode="discriminator")
+        assert model._dreal_cache is None                      # consumed (or discarded) by the D step
+        sum(d_losses.values()).backward()
+        torch.cuda.synchronize()
+        return model.netD.store.grad.clone(), {k: float(v.detach()) for k, v in d_losses.items()}
+
+    g_fresh, l_fresh = d_grads(False)
+    g_reuse, l_reuse = d_grads(True)
+    assert torch.equal(g_fresh, g_reuse)
+    assert all(abs(l_fresh[k] - l_reuse[k]) <= 1e-5 * abs(l_fresh[k]) for k in l_fresh)     # (loss sums use float atomics)
+    # stale cache: the image changes in place after the G step -> the D step must not use the old pass
+    with torch.no_grad():
+        model(data, mode="generator")
+    data["image"].mul_(0.5)
+    model.netD.store.zero_grad()
+    d_losses = model(data, mode="discriminator")
+    sum(d_losses.values()).backward()
+    g_changed = model.netD.store.grad.clone()
+    g_ref, _ = d_grads(False)
+    assert torch.equal(g_changed, g_ref) and not torch.equal(g_changed, g_fresh)
+    # ... and a netD weight refresh invalidates it too
+    with torch.no_grad():
+        model(data, mode="generator")
+    model.netD.store.repack()
+    key_before = model._dreal_cache["key"]
+    from s2p_amd.models.autograd_nodes import _dreal_key
+    assert _dreal_key(model, data["prev_image"], data["image"]) != key_before
 
 
 def test_trainer_steps_and_checkpoint(hip_device, tmp_path):
