@@ -1449,6 +1449,8 @@ static int conv_fwd_impl(const s2p_conv_desc* d, const void* x, const void* w_fw
   hipStream_t st = (hipStream_t)stream;
   int ce = d->dtype == S2P_F32 ? 4 : 8;
   if (epi == S2P_EPI_STORE && s2p_thin_applicable(d)) return sc.plan ? 0 : s2p_thin_fwd(d, x, w_fwd, bias, y, act, slope, st);
+  static const int no_cin = s2p_env_set("S2P_NO_THIN_CIN");          // A/B switch (diagnostics build only)
+  if (!no_cin && s2p_thin_cin_fwd_applicable(d, act, epi)) return sc.plan ? 0 : s2p_thin_cin_fwd(d, x, w_fwd, bias, y, act, slope, st);
   Geo G{d->N, d->H, d->W, d->Cin, d->x_pitch, d->x_gstride, d->Ho, d->Wo, d->Cout,
         /*Cst*/ d->groups == 1 ? ((d->Cout + ce - 1) / ce * ce <= d->y_pitch ? (d->Cout + ce - 1) / ce * ce : d->Cout)
                                : d->Cout,
@@ -1492,6 +1494,9 @@ static int conv_dgrad_impl(const s2p_conv_desc* d, const void* dy, const void* w
   int ce = d->dtype == S2P_F32 ? 4 : 8;
   int cout_pad = (d->Cout + ce - 1) / ce * ce;       // channels of dy actually gathered
   if (cout_pad > d->y_pitch) S2P_FAIL(-1, "s2p_conv2d_dgrad: dy pitch %d < padded Cout %d", d->y_pitch, cout_pad);
+  // thin input (<= 8 channels), stride 1: the adjoint is a thin-Cout conv over dy (row-streaming kernel, thin_rows.hip)
+  if (epi == S2P_EPI_STORE && s2p_thin_rows_dgrad_applicable(d, cout_pad))
+    return sc.plan ? 0 : s2p_thin_rows_dgrad(d, dy, w_bwd, dx, cout_pad, st);
   int H = d->H, W = d->W, pad = d->pad;
   if (d->reflect) { H += 2 * pad; W += 2 * pad; pad = 0; }
   Geo G{d->N, d->Ho, d->Wo, cout_pad, d->y_pitch, d->y_gstride, H, W, d->Cin, d->Cin,

@@ -135,6 +135,12 @@ int s2p_thin_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float*
 bool s2p_thin_rows_applicable(const s2p_conv_desc* d);
 int s2p_thin_rows_fwd(const s2p_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int act,
                       float slope, hipStream_t st);
+bool s2p_thin_rows_dgrad_applicable(const s2p_conv_desc* d, int cout_pad);
+int s2p_thin_rows_dgrad(const s2p_conv_desc* d, const void* dy, const void* w_bwd, void* dx, int cout_pad, hipStream_t st);
+// thin-input (Cin <= 8) forward convs (thin_rows.hip)
+bool s2p_thin_cin_fwd_applicable(const s2p_conv_desc* d, int act, int epi);
+int s2p_thin_cin_fwd(const s2p_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int act, float slope,
+                     hipStream_t st);
 // PatchGAN logit heads, Cout = 1 (wgrad_head.hip)
 bool s2p_head_wgrad_supported(const s2p_conv_desc* d, int cin_real, int cout_real);
 size_t s2p_head_wgrad_workspace(const s2p_conv_desc* d);

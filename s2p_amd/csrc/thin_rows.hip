@@ -21,6 +21,7 @@ struct RowsArgs {
   int N, H, W, x_pitch, Ho, Wo, y_pitch, pad, reflect, act;
   float slope;
   int band, nbands, nstrips, strip_out, nq;     // rows per band, bands per image, column strips, outputs per strip, row groups
+  int flip;                                     // taps read in reverse order (dgrad: the adjoint's kernel is the flipped one)
   unsigned img_bytes;                           // bytes of one image of x
   int diag;                                     // diagnostics build: 1 = no in-loop loads, 2 = no emission (timing only)
 };
@@ -34,7 +35,7 @@ __global__ __launch_bounds__(256, 1) void thin_rows_fwd_kernel(const RowsArgs a)
   constexpr int NJ = KS * CO;                   // MFMA rows in use: j = kx * CO + co
   constexpr int OPW = 32 - (KS - 1);            // outputs per wave
   constexpr int T = KS * KS;
-  static_assert(NJ <= 32, "KS * Cout must fit the 32 MFMA rows");
+  static_assert(NJ <= 32 && CO <= 8, "KS * Cout must fit the 32 MFMA rows, Cout one 16-byte chunk");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -51,7 +52,8 @@ __global__ __launch_bounds__(256, 1) void thin_rows_fwd_kernel(const RowsArgs a)
     u32x4 v = {0u, 0u, 0u, 0u};
     if (j < NJ) {
       const int kx = j / CO, co = j - kx * CO;
-      v = *(const u32x4*)(a.w + ((size_t)(co * T + ky * KS + kx) * CIN + s * 16 + hh * 8));
+      const int t = a.flip ? T - 1 - (ky * KS + kx) : ky * KS + kx;
+      v = *(const u32x4*)(a.w + ((size_t)(co * T + t) * CIN + s * 16 + hh * 8));
     }
     *(u32x4*)(Wf + (size_t)f * 16) = v;
   }
@@ -96,8 +98,9 @@ __global__ __launch_bounds__(256, 1) void thin_rows_fwd_kernel(const RowsArgs a)
 
   u32x4 cur[NS], nx1[NS], nx2[NS];
   load_row(0, cur); load_row(1, nx1); load_row(2, nx2);
-  const float bias_r[4] = {a.bias && CO > 0 ? a.bias[0] : 0.f, a.bias && CO > 1 ? a.bias[1] : 0.f,
-                           a.bias && CO > 2 ? a.bias[2] : 0.f, a.bias && CO > 3 ? a.bias[3] : 0.f};
+  float bias_r[CO];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) bias_r[co] = a.bias ? a.bias[co] : 0.f;
   const int ox = ox0 + wave * OPW + nl;         // output column of this lane (lanes nl < OPW of the lower half store)
   const bool store_lane = h == 0 && nl < OPW && ox < a.Wo;
 
@@ -108,7 +111,9 @@ __global__ __launch_bounds__(256, 1) void thin_rows_fwd_kernel(const RowsArgs a)
   // shifted sum over kx of a finished accumulator + bias + activation + store of output row `orel` of the band.
   // Branch-free (the store is predicated): the compiler is free to interleave it with the MFMAs of the next input row.
   auto emit = [&](const f32x16& d, int orel) {
-    float o[4] = {bias_r[0], bias_r[1], bias_r[2], bias_r[3]};
+    float o[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) o[co] = bias_r[co];
 #pragma unroll
     for (int kx = 0; kx < KS; ++kx)
 #pragma unroll
@@ -160,45 +165,234 @@ __global__ __launch_bounds__(256, 1) void thin_rows_fwd_kernel(const RowsArgs a)
   emit(acc[0], a.nq * KS - KS);                                // the row completed by the last input row
 }
 
-static bool rows_shape(const s2p_conv_desc* d) { return d->KH == 7 && d->Cout == 3 && d->Cin == 64; }
+// instantiated shapes: the generator's output conv (7x7, 64 -> 3) and, as the adjoint of VGG conv1_1 (3x3, 3 -> 64), a
+// 3x3 64 -> 8 conv with flipped taps
+static bool rows_shape(int KS, int cout, int cin) { return (KS == 7 && cout == 3 && cin == 64) || (KS == 3 && cout == 8 && cin == 64); }
 
 bool s2p_thin_rows_applicable(const s2p_conv_desc* d) {
   if (!(d->dtype == S2P_BF16 && d->groups == 1 && !d->transposed && d->stride == 1 && d->KH == d->KW && d->y_pitch == 8 &&
         d->x_pitch % 8 == 0))
     return false;
-  if (!rows_shape(d)) return false;
+  if (!rows_shape(d->KH, d->Cout, d->Cin)) return false;
   if (d->reflect && (d->pad >= d->H || d->pad >= d->W)) return false;
   if ((long long)d->H * d->W * d->x_pitch * 2 >= (1ll << 31)) return false;
   return d->Ho >= 1 && d->Wo >= 1;
 }
 
-int s2p_thin_rows_fwd(const s2p_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int act,
-                      float slope, hipStream_t st) {
+// geometry in "forward" terms: x [N,H,W,x_pitch] (CIN channels read), y [N,Ho,Wo,8]
+static int rows_launch(int KS, int cout, int cin, int N, int H, int W, int x_pitch, int Ho, int Wo, int pad, int reflect,
+                       int flip, const void* x, const void* w, const float* bias, void* y, int act, float slope, hipStream_t st) {
   RowsArgs a{};
   a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = bias; a.y = (__bf16*)y;
-  a.N = d->N; a.H = d->H; a.W = d->W; a.x_pitch = d->x_pitch; a.Ho = d->Ho; a.Wo = d->Wo; a.y_pitch = d->y_pitch;
-  a.pad = d->pad; a.reflect = d->reflect; a.act = act; a.slope = slope;
-  a.img_bytes = (unsigned)((long long)d->H * d->W * d->x_pitch * 2);
-  const int KS = d->KH;
-  const int opw = 32 - (KS - 1);
-  int nw = cdiv(d->Wo, opw);
-  if (nw > 4) nw = 4;
-  a.strip_out = opw * nw;
-  a.nstrips = cdiv(d->Wo, a.strip_out);
-  // row bands: one workgroup per CU when the batch allows (a band re-reads KS-1 halo rows)
+  a.N = N; a.H = H; a.W = W; a.x_pitch = x_pitch; a.Ho = Ho; a.Wo = Wo; a.y_pitch = 8;
+  a.pad = pad; a.reflect = reflect; a.act = act; a.slope = slope; a.flip = flip;
+  a.img_bytes = (unsigned)((long long)H * W * x_pitch * 2);
   static const int diag = s2p_env_int("S2P_DIAG", 0);
   a.diag = diag;
+  const int opw = 32 - (KS - 1);
+  int nw = cdiv(Wo, opw);
+  if (nw > 4) nw = 4;
+  a.strip_out = opw * nw;
+  a.nstrips = cdiv(Wo, a.strip_out);
+  // row bands: one workgroup per CU when the batch allows (a band re-reads KS-1 halo rows)
   static const int target = s2p_env_int("S2P_ROWS_WGS", 256);   // diagnostics build only
-  int nb = cdiv(target, (long long)d->N * a.nstrips);
+  int nb = cdiv(target, (long long)N * a.nstrips);
   if (nb < 1) nb = 1;
-  a.band = cdiv(d->Ho, nb);
-  if (a.band < KS) a.band = KS < d->Ho ? KS : d->Ho;
-  a.nbands = cdiv(d->Ho, a.band);
+  a.band = cdiv(Ho, nb);
+  if (a.band < KS) a.band = KS < Ho ? KS : Ho;
+  a.nbands = cdiv(Ho, a.band);
   a.nq = cdiv(a.band + KS - 1, KS);
-  const int NS = d->Cin / 16;
+  const int NS = cin / 16;
   const size_t lds = (size_t)KS * NS * 1024;
-  const dim3 grid((unsigned)(d->N * a.nbands * a.nstrips));
-  hipLaunchKernelGGL((thin_rows_fwd_kernel<7, 3, 64>), grid, dim3(64 * nw), lds, st, a);
+  const dim3 grid((unsigned)(N * a.nbands * a.nstrips));
+  if (KS == 7) hipLaunchKernelGGL((thin_rows_fwd_kernel<7, 3, 64>), grid, dim3(64 * nw), lds, st, a);
+  else hipLaunchKernelGGL((thin_rows_fwd_kernel<3, 8, 64>), grid, dim3(64 * nw), lds, st, a);
   S2P_CHECK_LAUNCH("thin_rows_fwd_kernel");
+  return 0;
+}
+
+int s2p_thin_rows_fwd(const s2p_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int act,
+                      float slope, hipStream_t st) {
+  return rows_launch(d->KH, d->Cout, d->Cin, d->N, d->H, d->W, d->x_pitch, d->Ho, d->Wo, d->pad, d->reflect, 0, x, w, bias, y, act,
+                     slope, st);
+}
+
+// dgrad of a stride-1 conv with a thin INPUT (Cin <= 8, e.g. VGG conv1_1: 3 -> 64): dx = conv(dy, flipped kernel), i.e. the
+// same row-streaming kernel run over dy with w_bwd ([Cin_pad][T][Cout_pad]) as its forward weight and the taps reversed
+bool s2p_thin_rows_dgrad_applicable(const s2p_conv_desc* d, int cout_pad) {
+  if (!(d->dtype == S2P_BF16 && d->groups == 1 && !d->transposed && !d->reflect && d->stride == 1 && d->KH == d->KW &&
+        d->x_pitch == 8 && d->Cin == 8 && d->y_pitch % 8 == 0))
+    return false;
+  if (!rows_shape(d->KH, 8, cout_pad)) return false;
+  if ((long long)d->Ho * d->Wo * d->y_pitch * 2 >= (1ll << 31)) return false;
+  return d->pad <= d->KH - 1;
+}
+
+int s2p_thin_rows_dgrad(const s2p_conv_desc* d, const void* dy, const void* w_bwd, void* dx, int cout_pad, hipStream_t st) {
+  return rows_launch(d->KH, 8, cout_pad, d->N, d->Ho, d->Wo, d->y_pitch, d->H, d->W, d->KH - 1 - d->pad, 0, 1, dy, w_bwd, nullptr, dx,
+                     S2P_ACT_NONE, 0.f, st);
+}
+
+// ================================================================================================================
+// Thin-INPUT convolutions with few taps (Cin <= 8 after padding, 3x3 / 4x4: VGG conv1_1, the 3 -> 1536 conditioning conv,
+// the PatchGAN first layer), forward, bf16.  The implicit GEMM has K = taps x 8; one v_mfma_f32_32x32x16_bf16 step
+// is TWO taps of one pixel column: the B fragment of lane (pixel, half) is the 16-byte pixel of tap 2s + half, loaded
+// straight from global memory (32 consecutive pixels of a row = 512 contiguous bytes: coalesced, and the 7 MB input stays
+// in L1 / L2 across its T re-reads) -- no LDS staging, no gather index tables.  The weights (64 output channels x K) sit
+// in LDS in fragment order.  A wave owns 32 consecutive output pixels x 64 channels; the two lane halves swap 8-byte
+// pieces at the end so that every store is a full 16-byte channel chunk.
+struct CinArgs {
+  const __bf16* x; const __bf16* w; const float* bias; __bf16* y;
+  int N, H, W, Ho, Wo, Cout, y_pitch, stride, pad, reflect, act;
+  float slope;
+  int M, tiles, x_bytes;
+};
+
+template <int KS>
+__global__ __launch_bounds__(256) void thin_cin_fwd_kernel(const CinArgs a) {
+  constexpr int T = KS * KS, NK = (T + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];         // [2 co tiles][NK] fragments of 64 lanes x 16 B
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int co_base = blockIdx.y * 64;
+  // weights -> fragment order.  The source is read linearly (16-byte chunk i = co * T + t of this block's 64 channels);
+  // the odd half of the last K step (T odd) and channels past Cout stay zero.
+  if (T & 1)
+    for (int f = tid; f < 2 * 32; f += 256)
+      *(u32x4*)(smem + ((size_t)((f >> 5) * NK + NK - 1) * 64 + 32 + (f & 31)) * 16) = (u32x4){0u, 0u, 0u, 0u};
+  for (int i = tid; i < 64 * T; i += 256) {
+    const int cl = i / T, t = i - cl * T, co = co_base + cl;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (co < a.Cout) v = *(const u32x4*)(a.w + ((size_t)co_base * T + i) * 8);
+    *(u32x4*)(smem + ((size_t)((cl >> 5) * NK + (t >> 1)) * 64 + (t & 1) * 32 + (cl & 31)) * 16) = v;
+  }
+  __syncthreads();
+  const int nl = lane & 31, h = lane >> 5;
+  const unsigned OOB = 0x80000000u;
+  __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const float ns = a.act == S2P_ACT_RELU ? 0.f : (a.act == S2P_ACT_LRELU ? a.slope : 1.f);
+  const int HoWo = a.Ho * a.Wo;
+  for (int tile = blockIdx.x * 4 + wave; tile < a.tiles; tile += gridDim.x * 4) {
+    const int m = tile * 32 + nl;
+    const bool mok = m < a.M;
+    const int mm = mok ? m : 0;
+    const int n = mm / HoWo, rr = mm - n * HoWo, oy = rr / a.Wo, ox = rr - oy * a.Wo;
+    unsigned rowoff[KS], coloff[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      int iy = oy * a.stride + k - a.pad, ix = ox * a.stride + k - a.pad;
+      bool yok = mok, xok = true;
+      if (a.reflect) {
+        iy = iy < 0 ? -iy : (iy >= a.H ? 2 * a.H - 2 - iy : iy);
+        ix = ix < 0 ? -ix : (ix >= a.W ? 2 * a.W - 2 - ix : ix);
+      } else {
+        yok = yok && iy >= 0 && iy < a.H; xok = ix >= 0 && ix < a.W;
+      }
+      rowoff[k] = yok ? (unsigned)(((n * a.H + iy) * a.W) * 16) : OOB;
+      coloff[k] = xok ? (unsigned)(ix * 16) : OOB;
+    }
+    // K steps in chunks of CH: the loads of chunk c+1 are in flight under the MFMAs of chunk c.  (Written out as a
+    // two-buffer pipeline: left to itself hipcc hoists all 2*NK weight fragments into registers and then waits for every
+    // pixel load right where it is issued.)
+    constexpr int CH = NK > 8 ? 5 : NK, NCHUNK = (NK + CH - 1) / CH;
+    auto load_step = [&](int s) -> u32x4 {
+      const int t0 = 2 * s, t1 = 2 * s + 1 < T ? 2 * s + 1 : T - 1;           // the odd half of the last step has zero weights
+      const unsigned o0 = rowoff[t0 / KS] | coloff[t0 % KS], o1 = rowoff[t1 / KS] | coloff[t1 % KS];
+      const unsigned s0 = rowoff[t0 / KS] + coloff[t0 % KS], s1 = rowoff[t1 / KS] + coloff[t1 % KS];
+      const unsigned off = h ? ((o1 & OOB) ? OOB : s1) : ((o0 & OOB) ? OOB : s0);
+      return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)off, 0, 0));
+    };
+    const char* wf = smem;
+    asm volatile("" : "+v"(wf));                         // opaque per tile: the fragment reads stay in the loop
+    f32x16 acc[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[ct][e] = 0.f;
+    u32x4 bq[2][CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) bq[0][i] = load_step(i);
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+      if (c + 1 < NCHUNK) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+          if ((c + 1) * CH + i < NK) bq[(c + 1) & 1][i] = load_step((c + 1) * CH + i);
+      }
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int s = c * CH + i;
+        if (s < NK) {
+          const bf16x8 bf = __builtin_bit_cast(bf16x8, bq[c & 1][i]);
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            const bf16x8 af = *(const bf16x8*)(wf + ((size_t)(ct * NK + s) * 64 + lane) * 16);
+            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[ct], 0, 0, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // bias + activation, pack to bf16: pk[ct][q] = channels co_base + 32 ct + 8 q + 4 h + (0..3) of this lane's pixel
+    u32x2 pk[2][4];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int co = co_base + ct * 32 + 8 * q + 4 * h + e;
+          float t = acc[ct][4 * q + e] + ((a.bias && co < a.Cout) ? a.bias[co] : 0.f);
+          v[e] = t > 0.f ? t : t * ns;
+        }
+        const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        pk[ct][q] = __builtin_bit_cast(u32x2, o);
+      }
+    // half 0 stores the chunks q = 0, 1 (it needs the partner's 8 bytes of those), half 1 the chunks q = 2, 3
+    __bf16* yp = a.y + (size_t)m * a.y_pitch;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const u32x2 give = h ? pk[ct][k] : pk[ct][2 + k];
+        u32x2 got;
+        got[0] = (unsigned)__shfl_xor((int)give[0], 32, 64); got[1] = (unsigned)__shfl_xor((int)give[1], 32, 64);
+        const u32x2 own = h ? pk[ct][2 + k] : pk[ct][k];
+        const u32x4 out = h ? (u32x4){got[0], got[1], own[0], own[1]} : (u32x4){own[0], own[1], got[0], got[1]};
+        const int co0 = co_base + ct * 32 + 8 * (2 * h + k);
+        if (mok && co0 < a.Cout) *(u32x4*)(yp + co0) = out;
+      }
+  }
+}
+
+bool s2p_thin_cin_fwd_applicable(const s2p_conv_desc* d, int act, int epi) {
+  if (!(d->dtype == S2P_BF16 && d->groups == 1 && !d->transposed && d->Cin == 8 && d->x_pitch == 8 && d->KH == d->KW))
+    return false;
+  if (!(d->KH == 3 || d->KH == 4)) return false;      // (7x7: 25 K steps -- the register-staged gather kernel is faster there)
+  if (epi != S2P_EPI_STORE || !(act == S2P_ACT_NONE || act == S2P_ACT_RELU || act == S2P_ACT_LRELU)) return false;
+  if (d->Cout % 8 || d->Cout < 32 || d->y_pitch % 8) return false;
+  if (d->reflect && (d->pad >= d->H || d->pad >= d->W)) return false;
+  return (long long)d->N * d->H * d->W * 16 < (1ll << 31) && (long long)d->N * d->Ho * d->Wo < (1ll << 31) - 64;
+}
+
+int s2p_thin_cin_fwd(const s2p_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int act, float slope,
+                     hipStream_t st) {
+  CinArgs a{};
+  a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = bias; a.y = (__bf16*)y;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.y_pitch = d->y_pitch;
+  a.stride = d->stride; a.pad = d->pad; a.reflect = d->reflect; a.act = act; a.slope = slope;
+  a.M = d->N * d->Ho * d->Wo; a.tiles = cdiv(a.M, 32);
+  a.x_bytes = (int)((long long)d->N * d->H * d->W * 16);
+  const int T = d->KH * d->KW, NK = (T + 1) / 2;
+  const int ncb = cdiv(d->Cout, 64);
+  int gx = cdiv(a.tiles, 4);
+  const int cap = 768 / ncb > 32 ? 768 / ncb : 32;            // ~3 workgroups per CU: each stages 2*NK KiB of weights once
+  if (gx > cap) gx = cap;
+  const dim3 grid(gx, ncb);
+  const size_t lds = (size_t)2 * NK * 1024;
+  if (d->KH == 4) hipLaunchKernelGGL(thin_cin_fwd_kernel<4>, grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL(thin_cin_fwd_kernel<3>, grid, dim3(256), lds, st, a);
+  S2P_CHECK_LAUNCH("thin_cin_fwd_kernel");
   return 0;
 }

@@ -65,6 +65,10 @@ CONV_CASES = [
     (64, 3, 7, 1, 3, False, True, 84, 84, 2),      # out conv, row-streaming path: 3 waves, several row bands
     (64, 3, 7, 1, 3, False, True, 9, 130, 1),      # row-streaming path: two column strips, one short band
     (64, 3, 7, 1, 3, False, False, 30, 40, 3),     # row-streaming path with zero padding
+    (3, 64, 3, 1, 1, False, False, 84, 84, 2),     # VGG conv1_1: the dgrad is the row-streaming kernel over dy with flipped taps
+    (3, 64, 3, 1, 1, False, False, 9, 35, 3),      # ... two waves, one short band
+    (3, 200, 3, 1, 1, False, False, 21, 21, 2),    # conditioning conv 3 -> many: thin-input forward kernel, 4 channel blocks (ragged)
+    (3, 64, 7, 1, 3, False, True, 84, 84, 1),      # stem at the train size: thin-input forward kernel, several tiles per wave
 ]
 
 

@@ -27,6 +27,7 @@ SHAPES = [
     ("N64 D2 128->256 s2 @12", 64, 12, 12, 128, 256, 4, 2, 2, 0, 0, 1),
     ("N64 vgg4_2 512->512 @10", 64, 10, 10, 512, 512, 3, 1, 1, 0, 0, 1),
     ("N64 vgg5_1 512->512 @5", 64, 5, 5, 512, 512, 3, 1, 1, 0, 0, 1),
+    ("vgg1_1 3->64 @84", 64, 84, 84, 3, 64, 3, 1, 1, 0, 0, 1),
     ("vgg1_2 64->64 @84 (2N)", 128, 84, 84, 64, 64, 3, 1, 1, 0, 0, 1),
     ("vgg2_2 128->128 @42", 128, 42, 42, 128, 128, 3, 1, 1, 0, 0, 1),
     ("vgg3_2 256->256 @21", 128, 21, 21, 256, 256, 3, 1, 1, 0, 0, 1),
