@@ -144,6 +144,9 @@ int s2p_thin_cin_fwd(const s2p_conv_desc* d, const void* x, const void* w, const
 // PatchGAN logit heads, Cout = 1 (wgrad_head.hip)
 bool s2p_head_wgrad_supported(const s2p_conv_desc* d, int cin_real, int cout_real);
 size_t s2p_head_wgrad_workspace(const s2p_conv_desc* d);
+bool s2p_head_fwd_applicable(const s2p_conv_desc* d);
+int s2p_head_fwd(const s2p_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int act, float slope,
+                 hipStream_t st);
 int s2p_head_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, float* db, int cin_real,
                    void* workspace, size_t workspace_bytes, hipStream_t st);
 

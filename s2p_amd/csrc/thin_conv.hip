@@ -162,6 +162,8 @@ bool s2p_thin_applicable(const s2p_conv_desc* d) {
 
 int s2p_thin_fwd(const s2p_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int act, float slope,
                  hipStream_t st) {
+  static const int no_head = s2p_env_set("S2P_NO_HEAD_FWD");          // A/B switch (diagnostics build only)
+  if (!no_head && s2p_head_fwd_applicable(d)) return s2p_head_fwd(d, x, w, bias, y, act, slope, st);
   static const int no_rows = s2p_env_set("S2P_NO_THIN_ROWS");         // A/B switch (diagnostics build only)
   if (!no_rows && act != S2P_ACT_SWISH && s2p_thin_rows_applicable(d)) return s2p_thin_rows_fwd(d, x, w, bias, y, act, slope, st);
   if (tiled_applicable(d)) return s2p_thin_tiled_fwd(d, x, w, bias, y, act, slope, st);
