@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define S2P_VERSION 107
+#define S2P_VERSION 108
 
 enum { S2P_F32 = 0, S2P_BF16 = 1 };
 enum { S2P_ACT_NONE = 0, S2P_ACT_RELU = 1, S2P_ACT_LRELU = 2, S2P_ACT_TANH = 3, S2P_ACT_SWISH = 4 };
@@ -224,6 +224,10 @@ int s2p_l1_loss(int dtype, const void* a, const void* b, int64_t count, float sc
  *   mode 2: loss += -scale*sum(x),       grad = -scale              (G)                */
 int s2p_hinge_loss(int dtype, const void* x, int64_t count, int mode, float scale,
                    float* loss_out, void* grad_x, void* stream);
+/* the same on an NHWC map x [pixels][pitch] whose channel 0 is the logit (the discriminator heads' output layout);
+ * grad_x (same layout, may be NULL): gradient in channel 0, zeros in the other channels                              */
+int s2p_hinge_loss_strided(int dtype, const void* x, int64_t pixels, int pitch, int mode, float scale,
+                           float* loss_out, void* grad_x, void* stream);
 
 /* ---- ensemble state-dynamics head (reference gaussian_ensemble.py:83-96 and
  *      state_transition_rollout.py:192-204) ------------------------------------------------

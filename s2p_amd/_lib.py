@@ -85,6 +85,7 @@ SIGNATURES = {
     "s2p_nhwc_to_u8": [c_int, _P, c_int, c_int64, c_int, _P, _P],
     "s2p_l1_loss": [c_int, _P, _P, c_int64, c_float, _P, _P, c_int, _P],
     "s2p_hinge_loss": [c_int, _P, c_int64, c_int, c_float, _P, _P, _P],
+    "s2p_hinge_loss_strided": [c_int, _P, c_int64, c_int, c_int, c_float, _P, _P, _P],
     "s2p_adam_step": [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int, c_float, _P],
     "s2p_ensemble_head": [_P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, _P,
                           _P, _P, _P],
@@ -123,7 +124,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the export is missing
             fn.argtypes = args
             fn.restype = _RESTYPE.get(name, c_int)
-        if L.s2p_version() < 107:
+        if L.s2p_version() < 108:
             raise RuntimeError("libs2p_hip.so is older than this package")
         _lib = L
     return _lib

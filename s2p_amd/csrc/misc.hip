@@ -369,6 +369,42 @@ extern "C" int s2p_hinge_loss(int dtype, const void* x, int64_t count, int mode,
   return 0;
 }
 
+// hinge terms straight on an NHWC logit map [pixels][pitch] whose channel 0 is the logit (the PatchGAN heads write pitch 8):
+// grad_x gets the gradient in channel 0 and zeros in the padding channels -- no NHWC -> dense -> NHWC round trip
+template <typename T>
+__global__ void hinge_strided_kernel(const T* x, long long pixels, int pitch, int mode, float scale, float* loss, T* grad) {
+  constexpr int CE = DT<T>::CE;
+  float s = 0.f;
+  GRID_STRIDE(p, pixels) {
+    const float v = to_f32(x[p * pitch]);
+    const float sgn = mode == 0 ? 1.f : -1.f;
+    const float t = 1.f + sgn * v;
+    const bool on = t > 0.f;
+    s += mode == 2 ? -v : (on ? t : 0.f);
+    if (grad) {
+      const float gr = mode == 2 ? -scale : (on ? sgn * scale : 0.f);
+      for (int c0 = 0; c0 < pitch; c0 += CE) {
+        Chunk<T> c; c.raw = (u32x4){0u, 0u, 0u, 0u};
+        if (c0 == 0) c.set(0, gr);
+        *(u32x4*)(grad + p * pitch + c0) = c.raw;
+      }
+    }
+  }
+  block_atomic_add(s * scale, loss);
+}
+extern "C" int s2p_hinge_loss_strided(int dtype, const void* x, int64_t pixels, int pitch, int mode, float scale, float* loss_out,
+                                      void* grad_x, void* stream) {
+  if (!x || !loss_out || mode < 0 || mode > 2) S2P_FAIL(-1, "s2p_hinge_loss_strided: bad argument");
+  const int ce = dtype == S2P_F32 ? 4 : 8;
+  if (pitch < ce || pitch % ce) S2P_FAIL(-1, "s2p_hinge_loss_strided: pitch must be a multiple of %d", ce);
+  dim3 g(grid_for(pixels, 256));                        // same-address atomic per workgroup: keep the grid small
+  if (dtype == S2P_F32) hipLaunchKernelGGL(hinge_strided_kernel<float>, g, dim3(256), 0, (hipStream_t)stream, (const float*)x, (long long)pixels, pitch, mode, scale, loss_out, (float*)grad_x);
+  else if (dtype == S2P_BF16) hipLaunchKernelGGL(hinge_strided_kernel<__bf16>, g, dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (long long)pixels, pitch, mode, scale, loss_out, (__bf16*)grad_x);
+  else S2P_FAIL(-1, "s2p_hinge_loss_strided: bad dtype");
+  S2P_CHECK_LAUNCH("hinge_strided_kernel");
+  return 0;
+}
+
 // ---- fused Adam over a flat fp32 buffer (28 B / parameter of HBM traffic) ----------------------------------
 __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long long n4, long long n, float lr_bc1,
                             float beta1, float beta2, float eps, float inv_sqrt_bc2, float gscale) {

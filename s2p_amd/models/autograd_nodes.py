@@ -144,19 +144,11 @@ def dreal_pass(model, prev_image, real_image, on_side):
     return dict(res=res, dctx=dctx, stream=side if on_side else None, key=_dreal_key(model, prev_image, real_image))
 
 
-def _hinge_seed(logits, mode_lo, mode_hi, N, num_D, loss_lo, loss_hi):
-    """logits: NHWC [2N,h,w,ce] (1 real channel).  Applies hinge mode_lo to the first N samples and mode_hi to the
-    last N (if not None); returns the gradient in the layout of `logits` ([N,...] only when mode_hi is None)."""
+def _hinge_seed(logits, mode, N, num_D, loss_slot):
+    """logits: NHWC [N,h,w,ce] (1 real channel).  loss_slot += hinge `mode` averaged over the map and over the num_D scales;
+    returns the gradient in the layout of `logits` (one launch, straight on the NHWC map)."""
     B, h, w, ce = logits.shape
-    keep = B if mode_hi is not None else N
-    dense = ops.nhwc_to_nchw(logits[:keep], 1)              # [keep,1,h,w] fp32
-    gd = torch.empty_like(dense)
-    cnt = N * h * w
-    sc = 1.0 / (cnt * num_D)
-    ops.hinge_loss(dense, cnt, mode_lo, sc, loss_lo, gd, x_off=0)
-    if mode_hi is not None:
-        ops.hinge_loss(dense, cnt, mode_hi, sc, loss_hi, gd, x_off=cnt)
-    return ops.nchw_to_nhwc(gd, logits.dtype, ce)
+    return ops.hinge_loss_nhwc(logits, mode, 1.0 / (N * h * w * num_D), loss_slot)
 
 
 class _GLossNode(torch.autograd.Function):
@@ -221,7 +213,7 @@ class _GLossNode(torch.autograd.Function):
         grads = []
         for feats, feats_r in zip(res, res_r):
             g = [None] * len(feats)
-            g[-1] = _hinge_seed(feats[-1], 2, None, N, num_D, losses[0:1], None)
+            g[-1] = _hinge_seed(feats[-1], 2, N, num_D, losses[0:1])
             if not opt.no_ganFeat_loss:
                 for j in range(len(feats) - 1):
                     f = feats[j]
@@ -305,7 +297,7 @@ class _DStepNode(torch.autograd.Function):
             grads = []
             for feats in res:
                 g = [None] * len(feats)
-                g[-1] = _hinge_seed(feats[-1], mode, None, N, num_D, loss_slot, None)
+                g[-1] = _hinge_seed(feats[-1], mode, N, num_D, loss_slot)
                 grads.append(g)
             return dctx, grads
 
@@ -324,7 +316,7 @@ class _DStepNode(torch.autograd.Function):
                 grads_r = []
                 for feats in cache["res"]:
                     g = [None] * len(feats)
-                    g[-1] = _hinge_seed(feats[-1], 1, None, N, num_D, losses[1:2], None)
+                    g[-1] = _hinge_seed(feats[-1], 1, N, num_D, losses[1:2])
                     grads_r.append(g)
                 cache = None
             else:

@@ -377,6 +377,16 @@ def hinge_loss(x, count, mode, scale, loss_out, grad_x=None, x_off=0):
     check(lib().s2p_hinge_loss(dtype_id(x.dtype), xp, count, mode, scale, ptr(loss_out), gp, stream()), "s2p_hinge_loss")
 
 
+def hinge_loss_nhwc(x, mode, scale, loss_out, want_grad=True):
+    """Hinge term on an NHWC logit map [B,h,w,pitch] (channel 0 = logit): loss_out += ..., returns the gradient in the
+    same layout (padding channels zero) or None."""
+    B, h, w, pitch = x.shape
+    g = torch.empty_like(x) if want_grad else None
+    check(lib().s2p_hinge_loss_strided(dtype_id(x.dtype), ptr(x), B * h * w, pitch, mode, scale, ptr(loss_out), ptr(g), stream()),
+          "s2p_hinge_loss_strided")
+    return g
+
+
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     check(lib().s2p_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale,
                               stream()), "s2p_adam_step")

@@ -345,6 +345,15 @@ def test_posenc_losses_adam(hip_device):
         ops.hinge_loss(x.to(dev), 300, mode, 0.5, l, gx)
         assert float(l) == pytest.approx(0.5 * float(fn(x)), rel=1e-5, abs=1e-3), (mode, float(l))
         assert torch.allclose(gx.cpu(), xr.grad)
+        # the same straight on an NHWC logit map (channel 0 of a pitch-8 bf16 tensor): one launch, gradient in place
+        xm = torch.zeros(3, 10, 10, 8); xm[..., 0] = x.bfloat16().float().reshape(3, 10, 10); xm[..., 1:] = 7.0
+        l2 = torch.zeros(1, device=dev)
+        gm = ops.hinge_loss_nhwc(xm.bfloat16().to(dev), mode, 0.5, l2)
+        xq = x.bfloat16().float().requires_grad_(True)
+        (fn(xq) * 0.5).backward()
+        assert float(l2) == pytest.approx(0.5 * float(fn(xq.detach())), rel=1e-5, abs=1e-3)
+        assert torch.equal(gm[..., 0].float().cpu().reshape(-1), xq.grad.bfloat16().float())
+        assert float(gm[..., 1:].float().abs().max()) == 0.0
     # Adam vs torch.optim.Adam
     p = torch.randn(1003, generator=g); gr = torch.randn(1003, generator=g)
     pt = p.clone().requires_grad_(True)
