@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define S2P_VERSION 108
+#define S2P_VERSION 109
 
 enum { S2P_F32 = 0, S2P_BF16 = 1 };
 enum { S2P_ACT_NONE = 0, S2P_ACT_RELU = 1, S2P_ACT_LRELU = 2, S2P_ACT_TANH = 3, S2P_ACT_SWISH = 4 };
@@ -218,6 +218,12 @@ int s2p_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n
  * a,b: `count` elements each (dtype)                                                    */
 int s2p_l1_loss(int dtype, const void* a, const void* b, int64_t count, float scale,
                 float* loss_out, void* grad_a, int accumulate, void* stream);
+/* n_jobs (<= S2P_L1_MAX_JOBS) such terms in one launch (the feature-matching maps of all PatchGAN scales, the VGG taps);
+ * `jobs` is a HOST array (copied into the kernel arguments).  Pointers 16-byte aligned, counts a multiple of the 16-byte
+ * chunk (8 bf16 / 4 fp32); grad_a is overwritten (no accumulate form).                                              */
+#define S2P_L1_MAX_JOBS 16
+typedef struct { const void* a; const void* b; void* grad_a; int64_t count; float scale; float* loss_out; } s2p_l1_job;
+int s2p_l1_loss_multi(int dtype, const s2p_l1_job* jobs, int n_jobs, void* stream);
 /* hinge terms on a D logit map x (count elements):
  *   mode 0: loss += scale*sum(relu(1+x)), grad = scale*(1+x>0)      (D on fake)
  *   mode 1: loss += scale*sum(relu(1-x)), grad = -scale*(1-x>0)     (D on real)

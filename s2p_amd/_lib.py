@@ -25,6 +25,11 @@ class ConvDesc(ctypes.Structure):
         "KH", "KW", "stride", "pad", "transposed", "reflect", "groups", "x_gstride", "y_gstride")]
 
 
+class L1Job(ctypes.Structure):
+    _fields_ = [("a", c_void_p), ("b", c_void_p), ("grad_a", c_void_p), ("count", c_int64), ("scale", c_float),
+                ("loss_out", c_void_p)]
+
+
 class WgradJob(ctypes.Structure):
     _fields_ = [("x", c_void_p), ("dy", c_void_p), ("dw", c_void_p), ("db", c_void_p)]
 
@@ -84,6 +89,7 @@ SIGNATURES = {
     "s2p_u8_to_nhwc": [c_int, _P, c_int64, c_int, _P, c_int, _P],
     "s2p_nhwc_to_u8": [c_int, _P, c_int, c_int64, c_int, _P, _P],
     "s2p_l1_loss": [c_int, _P, _P, c_int64, c_float, _P, _P, c_int, _P],
+    "s2p_l1_loss_multi": [c_int, ctypes.POINTER(L1Job), c_int, _P],
     "s2p_hinge_loss": [c_int, _P, c_int64, c_int, c_float, _P, _P, _P],
     "s2p_hinge_loss_strided": [c_int, _P, c_int64, c_int, c_int, c_float, _P, _P, _P],
     "s2p_adam_step": [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int, c_float, _P],
@@ -124,7 +130,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the export is missing
             fn.argtypes = args
             fn.restype = _RESTYPE.get(name, c_int)
-        if L.s2p_version() < 108:
+        if L.s2p_version() < 109:
             raise RuntimeError("libs2p_hip.so is older than this package")
         _lib = L
     return _lib

@@ -344,6 +344,52 @@ extern "C" int s2p_l1_loss(int dtype, const void* a, const void* b, int64_t coun
   S2P_CHECK_LAUNCH("l1_loss_kernel");
   return 0;
 }
+// several L1 terms in ONE launch (the 8 feature-matching maps of the two PatchGAN scales, the 5 VGG taps): blockIdx.y = job.
+// Every job needs 16-byte aligned pointers and a count that is a multiple of the chunk (NHWC activations are both).
+struct L1Multi { const void* a[S2P_L1_MAX_JOBS]; const void* b[S2P_L1_MAX_JOBS]; void* g[S2P_L1_MAX_JOBS];
+                 long long count[S2P_L1_MAX_JOBS]; float scale[S2P_L1_MAX_JOBS]; float* loss[S2P_L1_MAX_JOBS]; };
+template <typename T>
+__global__ void l1_multi_kernel(const L1Multi m) {
+  constexpr int CE = DT<T>::CE;
+  const int j = blockIdx.y;
+  const T* a = (const T*)m.a[j]; const T* b = (const T*)m.b[j]; T* grad = (T*)m.g[j];
+  const long long nch = m.count[j] / CE;
+  const float scale = m.scale[j];
+  float s = 0.f;
+  GRID_STRIDE(ci, nch) {
+    Chunk<T> av, bv, gv;
+    av.raw = *(const u32x4*)(a + ci * CE); bv.raw = *(const u32x4*)(b + ci * CE);
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+      const float d = av.get(e) - bv.get(e);
+      s += fabsf(d);
+      gv.set(e, d > 0.f ? scale : (d < 0.f ? -scale : 0.f));
+    }
+    if (grad) *(u32x4*)(grad + ci * CE) = gv.raw;
+  }
+  block_atomic_add(s * scale, m.loss[j]);
+}
+extern "C" int s2p_l1_loss_multi(int dtype, const s2p_l1_job* jobs, int n_jobs, void* stream) {
+  if (!jobs || n_jobs < 1 || n_jobs > S2P_L1_MAX_JOBS) S2P_FAIL(-1, "s2p_l1_loss_multi: 1..%d jobs", S2P_L1_MAX_JOBS);
+  const int ce = dtype == S2P_F32 ? 4 : 8;
+  L1Multi m{};
+  long long maxc = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    const s2p_l1_job& q = jobs[j];
+    if (!q.a || !q.b || !q.loss_out || q.count <= 0) S2P_FAIL(-1, "s2p_l1_loss_multi: job %d: null pointer / empty", j);
+    if (((unsigned long long)q.a | (unsigned long long)q.b | (unsigned long long)q.grad_a) & 15ull || q.count % ce)
+      S2P_FAIL(-1, "s2p_l1_loss_multi: job %d: pointers must be 16-byte aligned and count a multiple of %d", j, ce);
+    m.a[j] = q.a; m.b[j] = q.b; m.g[j] = q.grad_a; m.count[j] = q.count; m.scale[j] = q.scale; m.loss[j] = q.loss_out;
+    if (q.count > maxc) maxc = q.count;
+  }
+  // same-address atomics retire at ~13 ns each: <= 128 workgroups per job
+  dim3 g(grid_for(maxc / ce / 4, 128), n_jobs);
+  if (dtype == S2P_F32) hipLaunchKernelGGL(l1_multi_kernel<float>, g, dim3(256), 0, (hipStream_t)stream, m);
+  else if (dtype == S2P_BF16) hipLaunchKernelGGL(l1_multi_kernel<__bf16>, g, dim3(256), 0, (hipStream_t)stream, m);
+  else S2P_FAIL(-1, "s2p_l1_loss_multi: bad dtype");
+  S2P_CHECK_LAUNCH("l1_multi_kernel");
+  return 0;
+}
 template <typename T>
 __global__ void hinge_kernel(const T* x, long long count, int mode, float scale, float* loss, T* grad) {
   float s = 0.f;

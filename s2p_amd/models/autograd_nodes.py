@@ -192,11 +192,9 @@ class _GLossNode(torch.autograd.Function):
                 else:
                     taps_r, vctx_real = model.vgg.fwd_nhwc(real_nhwc)
                 taps, vctx = model.vgg.fwd_nhwc(fake)
-                tap_grads = []
-                for wk, t, tr in zip(VGG_WEIGHTS, taps, taps_r):
-                    tg = torch.empty_like(t)
-                    ops.l1_loss(t, tr, opt.lambda_vgg * wk / t.numel(), losses[2:3], tg)
-                    tap_grads.append(tg)
+                tap_grads = [torch.empty_like(t) for t in taps]
+                ops.l1_loss_multi([(t, tr, opt.lambda_vgg * wk / t.numel(), losses[2:3], tg)      # the 5 taps: one launch
+                                   for wk, t, tr, tg in zip(VGG_WEIGHTS, taps, taps_r, tap_grads)])
         # The discriminator sees the two halves of its batch as two passes of N (InstanceNorm is per-sample, so the
         # halves are independent): (prev, real) may already have been done under the generator forward (dreal_pass in
         # compute_generator_loss); otherwise it goes on its side stream now, next to the (prev, fake) pass.
@@ -210,7 +208,7 @@ class _GLossNode(torch.autograd.Function):
         res_r = dreal["res"]
         model._dreal_cache = dreal                 # the D step of this train step reuses it (same inputs, same netD weights)
         num_D = len(res)
-        grads = []
+        grads, fm_jobs = [], []
         for feats, feats_r in zip(res, res_r):
             g = [None] * len(feats)
             g[-1] = _hinge_seed(feats[-1], 2, N, num_D, losses[0:1])
@@ -218,9 +216,11 @@ class _GLossNode(torch.autograd.Function):
                 for j in range(len(feats) - 1):
                     f = feats[j]
                     gf = torch.empty_like(f)                 # gradient of the fake pass only (real features: detached)
-                    ops.l1_loss(f, feats_r[j], opt.lambda_feat / num_D / f.numel(), losses[1:2], gf)
+                    fm_jobs.append((f, feats_r[j], opt.lambda_feat / num_D / f.numel(), losses[1:2], gf))
                     g[j] = gf
             grads.append(g)
+        if fm_jobs:
+            ops.l1_loss_multi(fm_jobs)                       # the feature-matching maps of every scale: one launch
         if vgg_on_side:
             main.wait_stream(vs)
         ctx.vgg_on_side = vgg_on_side

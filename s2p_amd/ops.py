@@ -369,6 +369,20 @@ def l1_loss(a, b, scale, loss_out, grad_a=None, accumulate=False):
                             int(accumulate), stream()), "s2p_l1_loss")
 
 
+def l1_loss_multi(jobs):
+    """Several L1 terms in one launch.  jobs: list of (a, b, scale, loss_out, grad_a|None) with a, b contiguous NHWC
+    activations of one dtype; loss_out += scale * sum|a-b|, grad_a = scale * sign(a-b).  Lists longer than the kernel's job
+    table go out in several launches."""
+    cap = 16
+    for i0 in range(0, len(jobs), cap):
+        part = jobs[i0:i0 + cap]
+        arr = (_lib.L1Job * len(part))()
+        for i, (a, b, scale, loss_out, g) in enumerate(part):
+            assert a.dtype == part[0][0].dtype and a.numel() == b.numel()
+            arr[i] = _lib.L1Job(ptr(a), ptr(b), ptr(g), a.numel(), scale, ptr(loss_out))
+        check(lib().s2p_l1_loss_multi(dtype_id(part[0][0].dtype), arr, len(part), stream()), "s2p_l1_loss_multi")
+
+
 def hinge_loss(x, count, mode, scale, loss_out, grad_x=None, x_off=0):
     esz = x.element_size()
     xp = x.data_ptr() + x_off * esz

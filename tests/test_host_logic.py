@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_cabi_library_loads_and_exports_every_declared_symbol():
     L = _lib.lib()
-    assert L.s2p_version() >= 108
+    assert L.s2p_version() >= 109
     header = open(os.path.join(ROOT, "include", "s2p_hip.h")).read()
     declared = set(re.findall(r"\b(s2p_[a-z0-9_]+)\s*\(", header))
     declared -= {"s2p_conv_desc", "s2p_pack_job", "s2p_wgrad_job"}

@@ -337,6 +337,17 @@ def test_posenc_losses_adam(hip_device):
     ops.l1_loss(a.to(dev), b.to(dev), 0.25, loss, ga)
     assert abs(float(loss) - 0.25 * float((a - b).abs().sum())) < 1e-3
     assert torch.equal(ga.cpu(), 0.25 * torch.sign(a - b))
+    # several L1 terms in one launch (s2p_l1_loss_multi): different sizes, one job without a gradient, shared loss slot
+    shapes = [(2, 5, 5, 64), (2, 3, 3, 256), (1, 9, 7, 8)]
+    As = [torch.randn(sh, generator=g).bfloat16() for sh in shapes]; Bs = [torch.randn(sh, generator=g).bfloat16() for sh in shapes]
+    lm = torch.zeros(2, device=dev)
+    Gs = [torch.empty(sh, dtype=torch.bfloat16, device=dev) for sh in shapes[:2]] + [None]
+    dA, dB = [t.to(dev) for t in As], [t.to(dev) for t in Bs]
+    ops.l1_loss_multi([(dA[0], dB[0], 0.5, lm[0:1], Gs[0]), (dA[1], dB[1], 0.25, lm[0:1], Gs[1]), (dA[2], dB[2], 2.0, lm[1:2], None)])
+    want0 = 0.5 * float((As[0].float() - Bs[0].float()).abs().sum()) + 0.25 * float((As[1].float() - Bs[1].float()).abs().sum())
+    assert float(lm[0]) == pytest.approx(want0, rel=1e-5) and float(lm[1]) == pytest.approx(2.0 * float((As[2].float() - Bs[2].float()).abs().sum()), rel=1e-5)
+    assert torch.equal(Gs[0].float().cpu(), 0.5 * torch.sign(As[0].float() - Bs[0].float()))
+    assert torch.equal(Gs[1].float().cpu(), 0.25 * torch.sign(As[1].float() - Bs[1].float()))
     x = torch.randn(300, generator=g)
     for mode, fn in ((0, lambda v: F.relu(1 + v).sum()), (1, lambda v: F.relu(1 - v).sum()), (2, lambda v: -v.sum())):
         xr = x.clone().requires_grad_(True)
