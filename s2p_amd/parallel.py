@@ -11,24 +11,31 @@ import torch.distributed as dist
 
 
 class DataParallelGroup:
-    def __init__(self, rank=0, world_size=1, group=None):
+    def __init__(self, rank=0, world_size=1, group=None, active=None):
         self.rank, self.world_size, self.group = rank, world_size, group
+        # `active`: the exchange path runs (collectives, communication stream, graph cut points).  True with more than one
+        # rank -- and in the one-rank rehearsal (S2P_FORCE_DP=1), which drives the N>1 code over RCCL on a single GPU
+        self.active = (world_size > 1) if active is None else bool(active)
 
     @classmethod
     def from_env(cls, backend=None):
         ws = int(os.environ.get("WORLD_SIZE", "1"))
-        if ws <= 1:
+        forced = os.environ.get("S2P_FORCE_DP", "") not in ("", "0")
+        if ws <= 1 and not forced:
             return cls()
+        if ws <= 1:
+            os.environ.setdefault("MASTER_PORT", "29541")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if not dist.is_initialized():
             if backend is None:
                 backend = "nccl" if torch.cuda.is_available() else "gloo"
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group(backend=backend)
-        return cls(dist.get_rank(), dist.get_world_size())
+        return cls(dist.get_rank(), dist.get_world_size(), active=True)
 
     def all_reduce_(self, flat):
         """Sum `flat` over ranks in place (the 1/world factor is folded into the fused Adam's grad_scale)."""
-        if self.world_size > 1:
+        if self.active:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         return flat
 
@@ -45,7 +52,7 @@ class DataParallelGroup:
     def all_reduce_async(self, flat):
         """Sum `flat` over ranks on the communication stream, after everything issued so far on the current stream.
         Compute issued later on the current stream runs concurrently; call `join()` before it reads `flat`."""
-        if self.world_size <= 1:
+        if not self.active:
             return
         comm = self.comm_stream()
         comm.wait_stream(torch.cuda.current_stream())
@@ -54,21 +61,21 @@ class DataParallelGroup:
 
     def join(self):
         """Make the current stream wait for everything issued on the communication stream."""
-        if self.world_size > 1:
+        if self.active:
             torch.cuda.current_stream().wait_stream(self.comm_stream())
 
     def broadcast_store(self, store, src=0):
         """Make every rank start from rank `src`'s parameters (C2 in SURVEY.md section 2.2)."""
-        if self.world_size > 1:
+        if self.active:
             dist.broadcast(store.master, src=src, group=self.group)
             store.repack()
 
     def barrier(self):
-        if self.world_size > 1:
+        if self.active:
             dist.barrier(group=self.group)
 
     def max_over_ranks(self, value):
-        if self.world_size <= 1:
+        if not self.active:
             return value
         dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         t = torch.tensor([value], dtype=torch.float64, device=dev)

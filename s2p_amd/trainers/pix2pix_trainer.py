@@ -45,7 +45,7 @@ class Pix2PixTrainer:
             self.pix2pix_model.iters_done = int(ck.get("iters_done", 0)) if ck is not None else 0
             g_lr = self.optimizer_G.param_groups[0]["lr"]
             self.old_lr = g_lr if opt.no_TTUR else g_lr * 2
-            if self.dp.world_size > 1:
+            if self.dp.active:
                 self.pix2pix_model.netG.on_early_grads = self._allreduce_G_tail
         self.g_losses, self.d_losses = {}, {}
 
@@ -89,7 +89,7 @@ class Pix2PixTrainer:
 
     # ---- the two steps ---------------------------------------------------------------------------------------------------
     def run_generator_one_step(self, data):
-        multi = self.dp.world_size > 1
+        multi = self.dp.active
         self.optimizer_G.zero_grad()
         self.pix2pix_model.before_netD = self._wait_D_update if multi else None
         g_losses, generated = self.pix2pix_model(data, mode="generator")
@@ -105,7 +105,7 @@ class Pix2PixTrainer:
         self.optimizer_D.zero_grad()
         d_losses = self.pix2pix_model(data, mode="discriminator")
         self._backward(d_losses)
-        if self.dp.world_size > 1:
+        if self.dp.active:
             self._cut(self._finish_D_async)
         else:
             self.optimizer_D.step()
