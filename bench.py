@@ -138,6 +138,11 @@ def cpu_baseline(args, state_dim):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE JSON line (driver contract).  Native libraries write there too (RCCL prints a version banner
+    # on communicator creation): point fd 1 at stderr for the run and keep the real stdout for the result line.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -310,7 +315,8 @@ def main():
                        "vgg_weights": "seeded stand-in (ImageNet weights unobtainable offline)"},
             "roofline": roofline, "cpu_baseline": cpu, "losses": {k: round(v, 4) for k, v in losses.items()},
         }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

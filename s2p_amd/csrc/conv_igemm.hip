@@ -1227,8 +1227,17 @@ static int launch_fast(GatherArgs& a, int groups, hipStream_t st) {
   static const int diag = s2p_env_int("S2P_DIAG", 0);
   a.diag = diag;
   static const int no_halo = s2p_env_set("S2P_NO_HALO");        // A/B switch: plain LDS-DMA kernel
+  // launches that cannot fill the chip (<= 160 workgroups with a long K: PatchGAN 256->512 4x4 on 7x7 / 12x12 maps, VGG conv4_1 /
+  // conv5_1 on 10x10 / 5x5 maps): K split over blockIdx.z + fixed-order reduce with the epilogue, when the caller passed a
+  // scratch buffer.  One workgroup alone on a CU is bound by its LDS-DMA issue rate (~0.7 us per 32 KiB K step) whichever
+  // kernel runs it, so the K loop is spread over the idle CUs instead -- this takes precedence over the halo-resident kernel.
+  static const int no_split = s2p_env_set("S2P_NO_CONV_SPLITK");
+  int S_plan = 1;
+  if (!no_dma && !no_split && groups == 1 && a.nphase == 0 && a.ostride == 1 && a.oy0 == 0 && a.ox0 == 0 && a.Qh == a.Ho &&
+      a.Qw == a.Wo && (a.plan || a.ws))
+    S_plan = conv_split_plan((int)grid.x, a.Ktot / 64);
   if constexpr (BCO == 128 && BPIX == 128) {
-    if (!no_dma && !no_halo && a.istride == 1 && a.ostride == 1 && a.Qh == a.Hi && a.Qw == a.Wi && a.Ho == a.Qh &&
+    if (S_plan <= 1 && !no_dma && !no_halo && a.istride == 1 && a.ostride == 1 && a.Qh == a.Hi && a.Qw == a.Wi && a.Ho == a.Qh &&
         a.Wo == a.Qw && a.T >= 4) {
       if (a.plan) return 0;                              // halo-resident kernels: no scratch
       int lo = 0, hi = 0;
@@ -1253,17 +1262,10 @@ static int launch_fast(GatherArgs& a, int groups, hipStream_t st) {
       if (npos <= 320) { hipLaunchKernelGGL((conv_halo_kernel<320, false>), grid, dim3(256), 0, st, a); S2P_CHECK_LAUNCH("conv_halo_kernel"); return 0; }
     }
   }
-  // launches that cannot fill the chip (<= 160 workgroups, size-changing convs with a long K: PatchGAN 256->512 4x4 on 7x7 / 12x12 maps):
-  // K split over blockIdx.z + fixed-order reduce with the epilogue, when the caller passed a scratch buffer.  One
-  // workgroup alone on a CU is bound by its LDS-DMA issue rate (~0.7 us per 32 KiB K step), so the K loop is spread
-  // over the idle CUs instead.
-  static const int no_split = s2p_env_set("S2P_NO_CONV_SPLITK");
-  if (!no_dma && !no_split && groups == 1 && a.nphase == 0 && a.ostride == 1 && a.oy0 == 0 && a.ox0 == 0 && a.Qh == a.Ho &&
-      a.Qw == a.Wo && (a.plan || a.ws)) {
+  if (S_plan > 1) {
     const int nk = a.Ktot / 64;
-    const int S = conv_split_plan((int)grid.x, nk);
-    if (S > 1) {
-      a.psteps = cdiv(nk, S); a.psplit = cdiv(nk, a.psteps);
+    {
+      a.psteps = cdiv(nk, S_plan); a.psplit = cdiv(nk, a.psteps);
       a.part_m = a.npix_tiles * BPIX;
       const size_t need = (size_t)a.psplit * a.Cst * a.part_m * sizeof(float);
       if (a.plan) { if (need > *a.plan) *a.plan = need; return 0; }

@@ -11,6 +11,7 @@ from .. import ops
 from .._lib import chunk_elems
 
 
+DBWD_LANE = 0           # discriminator backward: coarser scales on this side-stream lane under scale 0 (None: one stream)
 OVERLAP_VGG = True      # VGG branch of the G loss on a side stream (tools/ab_step.py flips it for an A/B)
 
 
@@ -258,7 +259,7 @@ class _GLossNode(torch.autograd.Function):
                 dv = model.vgg.bwd_nhwc(ctx.vctx, ctx.tap_grads, N)
             if ctx.vgg_on_side:
                 dv.record_stream(main)
-        dx = model.netD.bwd_nhwc(ctx.dctx, ctx.grads, need_wgrad=False, need_dx=True)
+        dx = model.netD.bwd_nhwc(ctx.dctx, ctx.grads, need_wgrad=False, need_dx=True, lane=DBWD_LANE)
         ops.copy_channels(dx, 3, d_fake, 0, 3, accumulate=True, src_rows=N)
         if dv is not None:
             if ctx.vgg_on_side:
@@ -324,7 +325,7 @@ class _DStepNode(torch.autograd.Function):
                 # (no nested fork: HIP's stream capture crashed in hipStreamEndCapture with a side stream forked from a side stream)
                 dctx_r, grads_r = half(xr, 1, losses[1:2], None if use_side else 0)
             if unit and DREAL_EARLY_BWD:               # upstream gradient is 1: the real half's backward can go now
-                netD.bwd_nhwc(dctx_r, grads_r, need_wgrad=True, need_dx=False)
+                netD.bwd_nhwc(dctx_r, grads_r, need_wgrad=True, need_dx=False, lane=None if use_side else DBWD_LANE)
                 dctx_r = grads_r = None
         if fake_given is None:
             dt = netG.compute_dtype
@@ -352,8 +353,8 @@ class _DStepNode(torch.autograd.Function):
             for gs in ctx.grads_r:
                 ops.scale_(gs[-1], g[1:2])
         if ctx.dctx_r is not None:
-            netD.bwd_nhwc(ctx.dctx_r, ctx.grads_r, need_wgrad=True, need_dx=False)
-        netD.bwd_nhwc(ctx.dctx_f, ctx.grads_f, need_wgrad=True, need_dx=False)
+            netD.bwd_nhwc(ctx.dctx_r, ctx.grads_r, need_wgrad=True, need_dx=False, lane=DBWD_LANE)
+        netD.bwd_nhwc(ctx.dctx_f, ctx.grads_f, need_wgrad=True, need_dx=False, lane=DBWD_LANE)
         ctx.dctx_f = ctx.grads_f = ctx.dctx_r = ctx.grads_r = None
         return None, None, None, None, None, None
 

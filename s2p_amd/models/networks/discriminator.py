@@ -173,17 +173,52 @@ class MultiscaleDiscriminator(BaseNetwork):
             main.wait_stream(side)
         return result, ctx
 
-    def bwd_nhwc(self, ctx, grads, need_wgrad=True, need_dx=True, n_keep=None):
-        dx_next = None
-        for i in reversed(range(self.num_D)):
+    def bwd_nhwc(self, ctx, grads, need_wgrad=True, need_dx=True, n_keep=None, lane=None):
+        """Backward of every scale.  The scales write disjoint parameters and meet only in d(loss)/dx (the coarser scale's dx
+        is folded into the finer one's through the adjoint of the average pool), so with `lane` given the scales >= 1 run on
+        that lane's side stream under scale 0 -- same launches, same accumulation order as the one-stream form (lane None;
+        used when the caller is itself on a side stream: no nested forks)."""
+        main = torch.cuda.current_stream()
+        fork = lane is not None and not ops.SERIALIZE and self.num_D > 1
+        side = self._side_stream(lane) if fork else main
+        subs = self.subnets()
+
+        def one(i):
             x, saved = ctx[i]
-            if n_keep is not None:
-                x = x[:n_keep]
-            dx = self.subnets()[i].bwd_nhwc(saved, grads[i], need_wgrad=need_wgrad, need_dx=need_dx, n_keep=n_keep)
-            if need_dx:
-                if dx_next is not None:
-                    ops.avgpool_bwd(dx_next, tuple(x.shape), dx=dx, accumulate=True)
-                dx_next = dx
+            return subs[i].bwd_nhwc(saved, grads[i], need_wgrad=need_wgrad, need_dx=need_dx, n_keep=n_keep)
+
+        def xshape(i):
+            x = ctx[i][0]
+            return tuple((x[:n_keep] if n_keep is not None else x).shape)
+
+        dx_next = None
+        if fork:
+            side.wait_stream(main)
+            for i in range(1, self.num_D):                     # made on main or on a forward lane, read on `side`
+                x, saved = ctx[i]
+                for tup in saved:
+                    for t in tup:
+                        if t is not None and torch.is_tensor(t):
+                            t.record_stream(side)
+                for g in grads[i]:
+                    if g is not None:
+                        g.record_stream(side)
+        with torch.cuda.stream(side):
+            for i in reversed(range(1, self.num_D)):
+                dx = one(i)
+                if need_dx:
+                    if dx_next is not None:
+                        ops.avgpool_bwd(dx_next, xshape(i), dx=dx, accumulate=True)
+                    dx_next = dx
+            if fork and dx_next is not None:
+                dx_next.record_stream(main)
+        dx = one(0)
+        if fork:
+            main.wait_stream(side)
+        if need_dx:
+            if dx_next is not None:
+                ops.avgpool_bwd(dx_next, xshape(0), dx=dx, accumulate=True)
+            dx_next = dx
         return dx_next
 
     def forward(self, x):

@@ -1,6 +1,6 @@
 """Same-box A/B of Python-level switches on the full train step (box-to-box spread on this pool is +-3 %, so variants are
 compared inside ONE process: capture A, time it, capture B, time it, alternating).  Usage:
-    python tools/ab_step.py autograd_nodes.OVERLAP_VGG [rounds]"""
+    python tools/ab_step.py autograd_nodes.OVERLAP_VGG [rounds [valueA valueB]]      (values: Python literals, default True False)"""
 import os, sys, time, importlib
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import torch
@@ -11,6 +11,7 @@ import io, contextlib
 
 target = sys.argv[1] if len(sys.argv) > 1 else "autograd_nodes.OVERLAP_VGG"
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+vals = (eval(sys.argv[3]), eval(sys.argv[4])) if len(sys.argv) > 4 else (True, False)
 modname, attr = target.rsplit(".", 1)
 mod = importlib.import_module(modname if modname.startswith("s2p_amd") else "s2p_amd.models." + modname)
 opt = TrainOptions().parse(["--env_type", "cheetah", "--batchSize", "64", "--precision", "bf16", "--gpu_ids", "0",
@@ -43,11 +44,11 @@ def measure(val, n=30):
     return (time.perf_counter() - t0) / n * 1e3
 
 
-res = {True: [], False: []}
+res = {v: [] for v in vals}
 for r in range(rounds):
-    for val in (True, False):
+    for val in vals:
         res[val].append(measure(val))
         print("round %d  %s=%s  %.3f ms/step" % (r, target, val, res[val][-1]), flush=True)
-for val in (True, False):
+for val in vals:
     v = sorted(res[val])
     print("%s=%s: median %.3f ms  min %.3f ms" % (target, val, v[len(v) // 2], v[0]))
