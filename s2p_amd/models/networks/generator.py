@@ -21,8 +21,9 @@ from .base_network import BaseNetwork
 from .layers import ConvLayer
 
 LRELU = 0.2
-WGRAD_SIDE = False       # experiment (tools/ab_step.py): batched weight gradients on a side stream
-COND_SIDE = False        # experiment: image-conditioning branch on its own stream, concurrent with the encoder (measured neutral)
+WGRAD_SIDE = True        # deferred weight gradients on a side stream (A/B: tools/ab_step.py)
+WGRAD_CHUNK_BLOCKS = 2   # ... launched every this many finished ResBlks, under the rest of the backward chain (0: one batch behind it)
+COND_SIDE = True         # backward of the image-conditioning branch on its own stream, concurrent with the encoder backward
 
 
 class _Linear(nn.Module):
@@ -212,7 +213,7 @@ class S2PGenerator(BaseNetwork):
         # image conditioning (shared conv + the 12 gamma/beta heads as one grouped conv): independent of the encoder below, so
         # it runs on its own side stream, concurrently with it (both forked from the main stream: no nested forks)
         hq, wq = H >> self.n_down, W >> self.n_down
-        cs = self._cond_stream() if COND_SIDE else main
+        cs = self._cond_stream() if (COND_SIDE and not ops.SERIALIZE) else main
         if cs is not main:
             cs.wait_stream(main)
             img.record_stream(cs)
@@ -308,8 +309,28 @@ class S2PGenerator(BaseNetwork):
         # The 12 block convs' weight gradients do not feed the backward chain: they are deferred and run as ONE batched
         # launch behind it (12 x 16 output tiles x K-splits fill the chip without split-K 16 atomics); their dY tensors
         # (12 x 14 MB at bs 64) simply stay alive until then.
+        # With WGRAD_SIDE they go to a side stream in batches of WGRAD_CHUNK_BLOCKS blocks while the chain is still running:
+        # the chain alternates MFMA-bound convs (442 workgroups on 512 slots) with HBM-bound MAT backward passes, and the
+        # weight-gradient workgroups take the MFMA time those leave idle.
+        main = torch.cuda.current_stream()
+        ws = self._wgrad_stream() if (WGRAD_SIDE and not ops.SERIALIZE) else None
+
+        def side_wgrads(jobs, extra=None):
+            if ws is None:
+                ConvLayer.wgrad_many(jobs)
+                if extra is not None:
+                    extra()
+                return
+            ws.wait_stream(main)
+            for _, x, dy in jobs:
+                x.record_stream(ws); dy.record_stream(ws)
+            with torch.cuda.stream(ws):
+                ConvLayer.wgrad_many(jobs)
+                if extra is not None:
+                    extra()
+
         wjobs = []
-        for b in reversed(range(self.n_blocks)):
+        for k, b in enumerate(reversed(range(self.n_blocks))):
             x, sA, nA, c0, sB, nB = ctx["blocks"][b]
             o0, o1 = (2 * b) * 2 * C, (2 * b + 1) * 2 * C
             wjobs.append((L[f"b{b}c1"], nB, dx))
@@ -319,29 +340,27 @@ class S2PGenerator(BaseNetwork):
             d_nA = L[f"b{b}c0"].dgrad(d_c0, nA.shape)
             d_xb = ops.in_bwd(d_nA, x, C, sA, gb_all, o0, st_all, o0, ACT_LRELU, LRELU, dgb_all, o0, dst_all, o0)
             dx = ops.add(dx, d_xb, out=d_xb)
+            if ws is not None and WGRAD_CHUNK_BLOCKS > 0 and (k + 1) % WGRAD_CHUNK_BLOCKS == 0 and k + 1 < self.n_blocks:
+                side_wgrads(wjobs)
+                wjobs = []
         actv, seg = ctx["actv"], ctx["seg"]
-        main = torch.cuda.current_stream()
-        if WGRAD_SIDE and self.on_early_grads is None:
-            # (single rank) the two big batched weight-gradient launches overlap the rest of the backward on a side stream
-            ws = self._wgrad_stream()
-            ws.wait_stream(main)
-            with torch.cuda.stream(ws):
-                ConvLayer.wgrad_many(wjobs)
-                L["gb"].wgrad(actv, dgb_all)
-        else:
-            ws = None
-            ConvLayer.wgrad_many(wjobs)
-            # image-conditioning branch (batched)
-            L["gb"].wgrad(actv, dgb_all)
-            # every gradient of the flat buffer's tail [early_grad_offset, end) is final now (data-parallel hook: the trainer
-            # starts that bucket's all-reduce here, under the rest of this backward)
-            if self.on_early_grads is not None:
-                self.on_early_grads()
+        if ws is not None:
+            actv.record_stream(ws); dgb_all.record_stream(ws)
+        # the rest of the block convs' weight gradients + the image-conditioning branch's (batched)
+        side_wgrads(wjobs, lambda: L["gb"].wgrad(actv, dgb_all))
+        # every gradient of the flat buffer's tail [early_grad_offset, end) is final once these are done (data-parallel hook:
+        # the trainer starts that bucket's all-reduce here, under the rest of this backward; a graph segment ends at the
+        # hook, so the side stream re-joins first)
+        if self.on_early_grads is not None:
+            if ws is not None:
+                main.wait_stream(ws)
+                ws = None
+            self.on_early_grads()
         # backward of the image-conditioning branch on its side stream, concurrent with the encoder backward below
-        cs = self._cond_stream() if COND_SIDE else main
+        cs = self._cond_stream() if (COND_SIDE and not ops.SERIALIZE) else main
         if cs is not main:
             cs.wait_stream(main)
-            dgb_all.record_stream(cs)
+            dgb_all.record_stream(cs); actv.record_stream(cs)
         with torch.cuda.stream(cs):
             d_actv = L["gb"].dgrad(dgb_all, actv.shape, aux=actv, epi=EPI_MUL_ACTGRAD, aux_act=ACT_RELU)
             L["shared"].wgrad(seg, d_actv)

@@ -86,5 +86,11 @@ class StepGraph:
                 obj()
 
     @property
+    def capturing(self):
+        """True while `capture` is recording: kernels issued now are recorded, not run, so an eager action that mutates
+        state from their results (an optimizer step on freshly reduced gradients) must skip that part."""
+        return self._capturing
+
+    @property
     def n_graphs(self):
         return sum(1 for k, _ in self.seq if k == "graph")

@@ -82,7 +82,10 @@ class Pix2PixTrainer:
         comm.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(comm):
             dist.all_reduce(self.pix2pix_model.netD.store.grad, op=dist.ReduceOp.SUM, group=self.dp.group)
-            self.optimizer_D.step()
+            if not (self.seg is not None and self.seg.capturing):
+                # (while the step is being captured its kernels are only recorded: the gradients in the buffer are the
+                # previous step's, already applied -- a second update with them would be a spurious Adam step)
+                self.optimizer_D.step()
             ev = torch.cuda.Event()
             ev.record(comm)
         self._eD = ev

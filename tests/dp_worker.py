@@ -1,6 +1,7 @@
 """Child process of tests/test_dp_gpu.py: one data-parallel rank running ONE real Pix2PixTrainer G step + D step.
-Usage: python dp_worker.py RANK WORLD PORT OUTFILE   (all ranks share GPU 0; gloo carries the collectives, so the
-N>1 code path of trainer / parallel.py / FlatAdam runs on a one-GPU box exactly as it does over RCCL)."""
+Usage: python dp_worker.py RANK WORLD PORT OUTFILE [rccl]   (all ranks share GPU 0; gloo carries the collectives, so the
+N>1 code path of trainer / parallel.py / FlatAdam runs on a one-GPU box exactly as it does over RCCL.  With `rccl` and
+WORLD 1 the exchange path runs over a one-rank RCCL group instead: S2P_FORCE_DP, backend 'nccl')."""
 import os
 import sys
 
@@ -11,6 +12,10 @@ sys.path.insert(0, ROOT)
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    rccl = len(sys.argv) > 5 and sys.argv[5] == "rccl"
+    if rccl:
+        assert world == 1
+        os.environ["S2P_FORCE_DP"] = "1"                    # DataParallelGroup.from_env makes the one-rank 'nccl' group
     import torch
     import torch.distributed as dist
     from s2p_amd.options.train_options import TrainOptions
@@ -46,9 +51,10 @@ def main():
     torch.cuda.synchronize()
     losses = {k: float(v) for k, v in tr.get_latest_losses().items()}
     torch.save(dict(w0=w0, gG=gG, gD=gD, wG=wG, wD=model.netD.store.master.detach().cpu(),
-                    losses=losses, world=tr.dp.world_size, lrG=tr.optimizer_G.param_groups[0]["lr"],
+                    losses=losses, world=tr.dp.world_size, active=bool(tr.dp.active),
+                    backend=dist.get_backend() if dist.is_initialized() else None, lrG=tr.optimizer_G.param_groups[0]["lr"],
                     lrD=tr.optimizer_D.param_groups[0]["lr"]), out)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

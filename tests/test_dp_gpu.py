@@ -18,10 +18,10 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _run(world, tmp):
+def _run(world, tmp, extra=()):
     port = str(_free_port())
-    outs = [os.path.join(tmp, "w%d_r%d.pt" % (world, r)) for r in range(world)]
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), str(r), str(world), port, outs[r]],
+    outs = [os.path.join(tmp, "w%d_r%d%s.pt" % (world, r, "_".join(extra))) for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), str(r), str(world), port, outs[r], *extra],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     for p in procs:
         try:
@@ -83,3 +83,46 @@ def test_bench_two_ranks_segmented_graphs_rehearsal(hip_device, tmp_path):
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["config"]["global_batch"] == 8
     assert out["config"]["hip_graph"] is True and out["config"]["graph_segments"] >= 4, out["config"]
     assert all(v == v for v in out["losses"].values())
+
+
+def test_exchange_path_over_rccl_one_rank(hip_device, tmp_path):
+    """The N>1 exchange path over RCCL itself (backend 'nccl'), as far as a one-GPU box allows: S2P_FORCE_DP=1 makes a one-rank
+    RCCL group and drives the same code the driver's multi-GPU run takes -- parameter broadcast, the tail all-reduce launched
+    from the hook inside the generator backward, the head all-reduce behind it, D's all-reduce + Adam on the communication
+    stream.  With one rank every all-reduce is the identity and 1/world = 1: reduced gradients and updated weights must be
+    the plain single-process ones (same comparison as the 2-rank gloo test above)."""
+    single = _run(1, str(tmp_path))[0]
+    r = _run(1, str(tmp_path), extra=("rccl",))[0]
+    assert r["active"] and r["backend"] == "nccl" and not single["active"]
+    assert torch.equal(r["w0"], single["w0"])
+    for k in ("gG", "gD"):
+        err = float((r[k].double() - single[k].double()).norm() / single[k].double().norm())
+        print("one-rank RCCL vs plain %s: rel-L2 %.3e" % (k, err))
+        assert err < 1e-5, (k, err)
+    for wk, gk, lrk in (("wG", "gG", "lrG"), ("wD", "gD", "lrD")):
+        g = single[gk]
+        big = g.abs() > 0.05 * g.abs().max()
+        bad = int(((r[wk] - single[wk]).abs()[big] > 0.02 * single[lrk]).sum())
+        assert bad <= 1e-5 * int(big.sum()), (wk, bad)
+    for k, v in single["losses"].items():
+        assert abs(r["losses"][k] - v) <= 1e-4 * max(abs(v), 1e-2), (k, r["losses"][k], v)
+
+
+def test_bench_segmented_graphs_over_rccl_one_rank(hip_device, tmp_path):
+    """bench.py with the same one-rank RCCL group: the step is cut into hipGraph segments at every collective and replayed with
+    the RCCL launches in between; stdout must be exactly the one JSON line of the contract (RCCL prints a version banner on
+    communicator creation).  (Losses after several sign-like first Adam steps are not comparable between two runs -- see
+    dp_worker.py -- so the numerical check is the test above.)"""
+    import json
+    root = os.path.dirname(HERE)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "4", "--no-cpu-baseline",
+           "--no-roofline"]
+    env = dict(os.environ, S2P_FORCE_DP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[:2000]
+    dp = json.loads(lines[0])
+    assert dp["config"]["hip_graph"] is True and dp["config"]["graph_segments"] >= 4, dp["config"]
+    assert all(v == v and abs(v) < 1e4 for v in dp["losses"].values()), dp["losses"]

@@ -207,6 +207,36 @@ def test_generator_forward_backward(hip_device, tmp_path, precision, tol, gtol, 
     check_grads(grad_errors(dict(model.netG.named_parameters()), pg64m), gtol, f"G {precision}")
 
 
+def test_mat_resblock_each_block_in_isolation(hip_device, tmp_path):
+    """SURVEY.md section 8 row a3 (MATResnetBlock) on its own: every one of the 6 blocks is checked in isolation -- the float64
+    oracle block `O.mat_resblock` is fed the HIP path's OWN input of that block (saved activations of the fp32 forward), so an
+    error cannot hide behind, or be blamed on, the layers in front of it.  Checked per block: the first MAT norm + LeakyReLU
+    (nA), conv_0 (c0), the second MAT norm (nB) and the block output conv_1 + residual."""
+    opt, model, spec, pg, pd, pv = build("fp32", tmp_path)
+    prev, state, real = make_inputs(2, 84, 84, 17, seed=3)
+    y = model.netG(prev.cuda(), state.cuda())
+    c = y.grad_fn.next_functions[0][0].c
+    C = model.netG.c_mid
+    pg64 = {k: v.double() for k, v in pg.items()}
+    w64 = O.state_mapping(pg64, state.double(), spec)
+    blocks = c["blocks"]
+    assert len(blocks) == spec.n_blocks == 6
+    outs = [_nchw(blocks[b + 1][0], C) for b in range(len(blocks) - 1)] + [_nchw(c["dec"][0][0], C)]   # x of the next block / decoder input
+    worst = 0.0
+    for b, (x, sA, nA, c0, sB, nB) in enumerate(blocks):
+        x64 = _nchw(x, C).double()
+        tr = {}
+        ref = O.mat_resblock(pg64, b, x64, prev.double(), w64, trace=tr)
+        lre = torch.nn.functional.leaky_relu
+        errs = dict(nA=rel_l2(_nchw(nA, C), lre(tr[f"blocks.{b}.norm_0"], 0.2)), c0=rel_l2(_nchw(c0, C), tr[f"blocks.{b}.conv_0"]),
+                    nB=rel_l2(_nchw(nB, C), lre(tr[f"blocks.{b}.norm_1"], 0.2)), out=rel_l2(outs[b], ref))
+        print("MAT-ResBlk %d (isolated, fp32 vs float64): %s" % (b, {k: "%.1e" % v for k, v in errs.items()}))
+        worst = max(worst, *errs.values())
+        for k, v in errs.items():
+            assert v < 1e-5, (b, k, v)
+    assert worst > 0.0            # the comparison saw real data
+
+
 def test_generator_forward_is_bitwise_reproducible(hip_device, tmp_path):
     """No atomics on the bf16 generator forward path (IN statistics are merged in a fixed order): two runs agree bit for bit."""
     opt, model, spec, pg, pd, pv = build("bf16", tmp_path)
