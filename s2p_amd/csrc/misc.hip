@@ -582,12 +582,19 @@ __device__ void pack_one(const s2p_pack_job& j, int part, int nparts, float (*ti
 __global__ __launch_bounds__(256) void pack_kernel(const s2p_pack_job* jobs) {
   __shared__ float tile[32][33];
   const s2p_pack_job j = jobs[blockIdx.y];
-  if (j.dtype == S2P_F32) pack_one<float>(j, blockIdx.x, gridDim.x, tile);
-  else pack_one<__bf16>(j, blockIdx.x, gridDim.x, tile);
+  // the grid is sized for the largest job (2048 elements per workgroup); a smaller job uses only as many workgroups as it
+  // has 2048-element parts and the rest return at once (the jobs of one network differ by 4 orders of magnitude in size)
+  const long long el = (long long)j.R * j.T * (j.Cpad > j.C ? j.Cpad : j.C);
+  long long need = (el + 2047) / 2048;
+  if (need > (long long)gridDim.x) need = gridDim.x;
+  if (need < 1) need = 1;
+  if ((long long)blockIdx.x >= need) return;
+  if (j.dtype == S2P_F32) pack_one<float>(j, blockIdx.x, (int)need, tile);
+  else pack_one<__bf16>(j, blockIdx.x, (int)need, tile);
 }
 extern "C" int s2p_pack_weights(const s2p_pack_job* jobs, int n_jobs, int max_elems, void* stream) {
   if (!jobs || n_jobs <= 0) S2P_FAIL(-1, "s2p_pack_weights: bad argument");
-  int parts = (max_elems + 256 * 8 - 1) / (256 * 8); if (parts < 1) parts = 1; if (parts > 64) parts = 64;
+  int parts = (max_elems + 256 * 8 - 1) / (256 * 8); if (parts < 1) parts = 1; if (parts > 2048) parts = 2048;
   hipLaunchKernelGGL(pack_kernel, dim3(parts, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs);
   S2P_CHECK_LAUNCH("pack_kernel");
   return 0;
