@@ -317,6 +317,11 @@ def main():
         }
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():       # orderly RCCL teardown: every rank leaves together
+        trainer.sync(); torch.cuda.synchronize()
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

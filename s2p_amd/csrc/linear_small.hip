@@ -23,6 +23,8 @@ struct LinArgs {
   int K, xin_pitch, dy_pitch, yact_pitch, dw_row, k_real;
 };
 
+typedef __attribute__((address_space(3))) volatile float lds_cvf;      // LDS, one ds_read_b32 per access
+
 __device__ __forceinline__ float lin_actgrad(float yv, int act, float slope) {
   return act == S2P_ACT_LRELU ? (yv > 0.f ? 1.f : slope) : (act == S2P_ACT_RELU ? (yv > 0.f ? 1.f : 0.f) : 1.f);
 }
@@ -71,11 +73,16 @@ __device__ __forceinline__ void lin_gemm_tile(const LinArgs& a, int mb, int nb, 
       for (int e = 0; e < 4; ++e) ws[r * LD + q * 4 + e] = v[e];
     }
     __syncthreads();
+    // LDS is read one dword at a time (volatile: no ds_read_b128 / ds_read2_b64).  Measured on MI355X: when one of the
+    // LDS-DMA conv kernels (buffer_load ... lds) shares the CU -- the state path runs on a side stream beside them -- the
+    // wide reads hipcc forms here (rows of 65 floats: every 4th row is 16-byte aligned) return wrong data in lanes 48..63:
+    // 30 of 30 results differ, ~1 % of a partial sum; dword reads: 0 of 30 (tests/tools/repro_lds.py, tests/test_kernels_gpu.py).
+    const lds_cvf* xv = (const lds_cvf*)xs; const lds_cvf* wvp = (const lds_cvf*)ws;
 #pragma unroll 8
     for (int k = 0; k < KC; ++k) {
-      const float wv = ws[c * LD + k];
+      const float wv = wvp[c * LD + k];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = __builtin_fmaf(xs[(4 * mq + i) * LD + k], wv, acc[i]);
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_fmaf(xv[(4 * mq + i) * LD + k], wv, acc[i]);
     }
   }
 }
@@ -157,10 +164,11 @@ __global__ __launch_bounds__(256) void lin_wgrad_kernel(const LinArgs a) {
     }
     __syncthreads();
     const int mlim = a.M - mb < 64 ? a.M - mb : 64;
+    const lds_cvf* xv = (const lds_cvf*)xs; const lds_cvf* dv = (const lds_cvf*)ds;        // dword LDS reads only (see lin_gemm_tile)
     for (int m = 0; m < mlim; ++m) {
-      const float d = ds[m * 17 + c];
+      const float d = dv[m * 17 + c];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = __builtin_fmaf(d, xs[m * 65 + 4 * kq + i], acc[i]);
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_fmaf(d, xv[m * 65 + 4 * kq + i], acc[i]);
       accb += d;
     }
   }

@@ -18,6 +18,7 @@ from .generator import _Conv
 from .layers import ConvLayer
 
 LRELU = 0.2
+DFWD_SIDE = True         # forward: coarser scales on a side stream under scale 0 (diagnostic switch)
 
 
 class NLayerDiscriminator(BaseNetwork):
@@ -150,7 +151,7 @@ class MultiscaleDiscriminator(BaseNetwork):
         scales >= 1 run on a side stream, overlapped with scale 0 (fork/join captured by hipGraph)."""
         self._require_ready()
         main = torch.cuda.current_stream()
-        side = self._side_stream(lane) if (lane is not None and not ops.SERIALIZE) else main   # lane None: one stream
+        side = self._side_stream(lane) if (lane is not None and DFWD_SIDE and not ops.SERIALIZE) else main   # lane None: one stream
         subs = self.subnets()
         xs = [x]
         for i in range(1, self.num_D):

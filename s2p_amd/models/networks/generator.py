@@ -23,6 +23,8 @@ from .layers import ConvLayer
 LRELU = 0.2
 WGRAD_SIDE = True        # deferred weight gradients on a side stream (A/B: tools/ab_step.py)
 WGRAD_CHUNK_BLOCKS = 2   # ... launched every this many finished ResBlks, under the rest of the backward chain (0: one batch behind it)
+STATE_SIDE_FWD = True    # state path on its side stream in the forward / in the backward (diagnostic switches)
+STATE_SIDE_BWD = True
 COND_SIDE = True         # backward of the image-conditioning branch on its own stream, concurrent with the encoder backward
 
 
@@ -194,7 +196,7 @@ class S2PGenerator(BaseNetwork):
         # state path: a chain of tiny fp32 GEMMs (2..48 workgroups each).  It is independent of the image-conditioning
         # convs and the encoder, so it runs on a side stream and overlaps them (the fork/join is captured by hipGraph).
         main = torch.cuda.current_stream()
-        side = self._side_stream()
+        side = self._side_stream() if STATE_SIDE_FWD else main
         side.wait_stream(main)
         with torch.cuda.stream(side):
             # dedicated small-M fp32 kernels (csrc/linear_small.hip): one ~4 us launch per layer
@@ -365,7 +367,7 @@ class S2PGenerator(BaseNetwork):
             d_actv = L["gb"].dgrad(dgb_all, actv.shape, aux=actv, epi=EPI_MUL_ACTGRAD, aux_act=ACT_RELU)
             L["shared"].wgrad(seg, d_actv)
         # state path backward on the side stream, overlapped with the encoder backward below
-        side = self._side_stream()
+        side = self._side_stream() if STATE_SIDE_BWD else main
         side.wait_stream(main)
         dst_all.record_stream(side)
         with torch.cuda.stream(side):

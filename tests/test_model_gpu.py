@@ -645,3 +645,55 @@ def test_train_cli_epochs_checkpoint_and_resume(hip_device, tmp_path, graph):
     with pytest.raises(FileNotFoundError):
         train.main(["--env_type=walker", "--dataroot=" + os.path.join(root, "datasets"), "--gpu_ids=0", "--checkpoints_dir",
                     str(tmp_path), "--continue_train"])
+
+
+def test_small_kernels_are_undisturbed_by_lds_dma_kernels_on_the_same_cus(hip_device, tmp_path):
+    """Regression for a co-residency hazard found on MI355X: while one of the LDS-DMA conv kernels (`buffer_load ... lds`) runs on
+    another stream and shares CUs with them, the state path's linear kernels returned wrong data for the wide LDS reads
+    (ds_read_b128 / ds_read2_b64) hipcc had formed -- lanes 48..63, ~1 % of a partial sum, 30 of 30 runs -- which made the
+    state-MLP gradients of the overlapped train step differ by 1-10 % from run to run.  They now read LDS one dword at a time.
+    Here every small LDS-using kernel of the step runs on a side stream while a halo-resident ResBlk conv occupies the main
+    stream, and must reproduce its quiet result bit for bit."""
+    from s2p_amd import ops
+    opt, model, spec, pg, pd, pv = build("bf16", tmp_path)
+    L = model.netG.lay
+    g = torch.Generator().manual_seed(0)
+    bf = torch.bfloat16
+    a21 = torch.randn(64, 21, 21, 256, generator=g).to(bf).cuda()
+    a84 = torch.randn(64, 84, 84, 64, generator=g).to(bf).cuda()
+    seg = torch.zeros(64, 21, 21, 8, dtype=bf).cuda(); seg[..., :3] = torch.randn(64, 21, 21, 3, generator=g).to(bf).cuda()
+    f512 = torch.randn(64, 13, 13, 512, generator=g).to(bf).cuda()
+    M, K, N = 64, 256, 6144
+    x = torch.randn(M, K, generator=g).cuda(); dy = torch.randn(M, N, generator=g).cuda(); y = torch.randn(M, N, generator=g).cuda()
+    w_bwd = torch.randn(1, K, 1, N, generator=g).cuda().contiguous(); w_fwd = torch.randn(1, N, 1, K, generator=g).cuda().contiguous()
+    bias = torch.randn(N, generator=g).cuda()
+    head = model.netD.subnets()[0].lay[-1]
+
+    def lin_bwd():
+        dw = torch.zeros(N * K, device="cuda"); db = torch.zeros(N, device="cuda")
+        dx = ops.linear_bwd(x, dy, y, w_bwd, K, K, N, 2, 0.2, dw, db)
+        return torch.cat([dx.flatten(), dw, db])
+
+    victims = {
+        "linear_fwd (state affine 256 -> 6144)": lambda: ops.linear_fwd(x, w_fwd, bias, K, N, 2, 0.2),
+        "linear_bwd (wgrad + split-K dgrad)": lin_bwd,
+        "fused InstanceNorm forward": lambda: ops.in_norm_fwd(a21, 256, act=1)[0],
+        "thin-input conv 3 -> 1536 (conditioning)": lambda: L["shared"].fwd(seg, act=1),
+        "row-streaming 7x7 64 -> 3 (output conv)": lambda: L["out"].fwd(a84, act=3),
+        "PatchGAN logit head": lambda: head.fwd(f512),
+    }
+    side = torch.cuda.Stream()
+    for name, fn in victims.items():
+        torch.cuda.synchronize()
+        quiet = fn().clone()
+        torch.cuda.synchronize()
+        bad = 0
+        for it in range(8):
+            for _ in range(6):
+                L["b0c0"].fwd(a21)                       # LDS-DMA kernel on the main stream ...
+            with torch.cuda.stream(side):
+                out = fn()                               # ... while the small kernel runs beside it
+            torch.cuda.synchronize()
+            bad += int(not torch.equal(out, quiet))
+        print("%-44s: %d of 8 concurrent results differ from the quiet one" % (name, bad))
+        assert bad == 0, name
