@@ -76,7 +76,8 @@ __device__ __forceinline__ void lin_gemm_tile(const LinArgs& a, int mb, int nb, 
     // LDS is read one dword at a time (volatile: no ds_read_b128 / ds_read2_b64).  Measured on MI355X: when one of the
     // LDS-DMA conv kernels (buffer_load ... lds) shares the CU -- the state path runs on a side stream beside them -- the
     // wide reads hipcc forms here (rows of 65 floats: every 4th row is 16-byte aligned) return wrong data in lanes 48..63:
-    // 30 of 30 results differ, ~1 % of a partial sum; dword reads: 0 of 30 (tests/tools/repro_lds.py, tests/test_kernels_gpu.py).
+    // 30 of 30 results differ, ~1 % of a partial sum; dword reads: 0 of 30 (tests/tools/repro_lds.py, tests/test_model_gpu.py).
+    // Initialising M0 does not help (tried); kernels that use LDS-DMA themselves, the norm / thin / head kernels are unaffected.
     const lds_cvf* xv = (const lds_cvf*)xs; const lds_cvf* wvp = (const lds_cvf*)ws;
 #pragma unroll 8
     for (int k = 0; k < KC; ++k) {
