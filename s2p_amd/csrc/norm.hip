@@ -502,9 +502,11 @@ __global__ __launch_bounds__(1024) void in_fused_bwd_kernel(const NormArgs a) {
 }
 
 // per-channel sum over pixels (bias gradient)
+// part == nullptr: the pixel blocks add to db with fp32 atomics; otherwise block y stores its sums to part[y][Cs] (Cs = C rounded
+// up to 64) and channel_sum_reduce_kernel adds them in block order: bitwise reproducible
 template <typename T>
 __global__ __launch_bounds__(256) void channel_sum_kernel(const T* dy, long long pixels, int C, int pitch,
-                                                          float* db, int rows_per_block) {
+                                                          float* db, int rows_per_block, float* part) {
   constexpr int CE = DT<T>::CE;
   constexpr int CS = 64, NCH = CS / CE, PR = 256 / NCH;
   __shared__ float red[PR][CS + 1];
@@ -532,8 +534,16 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const T* dy, long long
     float s = 0.f;
     for (int i = 0; i < PR; ++i) s += red[i][tid];
     int c = blockIdx.x * CS + tid;
-    if (c < C) atomicAdd(db + c, s);
+    if (part) part[(size_t)blockIdx.y * (gridDim.x * CS) + c] = s;
+    else if (c < C) atomicAdd(db + c, s);
   }
+}
+__global__ __launch_bounds__(256) void channel_sum_reduce_kernel(const float* part, int nblk, int Cs, int C, float* db) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += part[(size_t)b * Cs + c];
+  db[c] += s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -688,21 +698,42 @@ extern "C" int s2p_in_norm_bwd(int dtype, const void* da, int da_pitch, const vo
   return 0;
 }
 
-extern "C" int s2p_channel_sum(int dtype, const void* dy, int64_t pixels, int C, int pitch, float* db,
-                               void* stream) {
+static void channel_sum_geom(int64_t pixels, int C, int& nb, int& rows) {
+  nb = (int)((pixels + 2047) / 2048); if (nb > 256) nb = 256; if (nb < 1) nb = 1;
+  rows = (int)((pixels + nb - 1) / nb);
+  nb = (int)((pixels + rows - 1) / rows);
+}
+// scratch bytes of the atomics-free form (s2p_channel_sum_det)
+size_t s2p_channel_sum_ws_bytes(int64_t pixels, int C) {
+  if (pixels <= 0 || C <= 0) return 0;
+  int nb, rows; channel_sum_geom(pixels, C, nb, rows);
+  return (size_t)nb * cdiv(C, 64) * 64 * sizeof(float);
+}
+// db[c] += sum over pixels of dy[p][c].  ws == nullptr (or too small): fp32 atomics; otherwise partial sums + a fixed-order reduce.
+int s2p_channel_sum_det(int dtype, const void* dy, int64_t pixels, int C, int pitch, float* db, void* ws, size_t ws_bytes,
+                        void* stream) {
   if (dtype != S2P_F32 && dtype != S2P_BF16) S2P_FAIL(-1, "s2p_channel_sum: bad dtype");
   int ce = dtype == S2P_F32 ? 4 : 8;
   if (pitch % ce) S2P_FAIL(-1, "s2p_channel_sum: pitch must be a multiple of %d", ce);
   if (pixels <= 0) return 0;
-  int nb = (int)((pixels + 2047) / 2048); if (nb > 256) nb = 256;
-  int rows = (int)((pixels + nb - 1) / nb);
-  dim3 grid(cdiv(C, 64), cdiv(pixels, rows));
+  int nb, rows; channel_sum_geom(pixels, C, nb, rows);
+  dim3 grid(cdiv(C, 64), nb);
+  float* part = (ws && ws_bytes >= s2p_channel_sum_ws_bytes(pixels, C) && nb > 1) ? (float*)ws : nullptr;
   if (dtype == S2P_F32)
     hipLaunchKernelGGL(channel_sum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dy,
-                       (long long)pixels, C, pitch, db, rows);
+                       (long long)pixels, C, pitch, db, rows, part);
   else
     hipLaunchKernelGGL(channel_sum_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)dy,
-                       (long long)pixels, C, pitch, db, rows);
+                       (long long)pixels, C, pitch, db, rows, part);
   S2P_CHECK_LAUNCH("channel_sum_kernel");
+  if (part) {
+    hipLaunchKernelGGL(channel_sum_reduce_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, part, nb, (int)grid.x * 64, C, db);
+    S2P_CHECK_LAUNCH("channel_sum_reduce_kernel");
+  }
   return 0;
+}
+
+extern "C" int s2p_channel_sum(int dtype, const void* dy, int64_t pixels, int C, int pitch, float* db,
+                               void* stream) {
+  return s2p_channel_sum_det(dtype, dy, pixels, C, pitch, db, nullptr, 0, stream);
 }

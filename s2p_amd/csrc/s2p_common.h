@@ -130,7 +130,10 @@ __device__ __forceinline__ void s2p_dma16(i32x4 rsrc, unsigned lds_dst, int voff
 bool s2p_thin_applicable(const s2p_conv_desc* d);
 int s2p_thin_fwd(const s2p_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int act, float slope,
                  hipStream_t st);
-int s2p_thin_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, int cin_real, hipStream_t st);
+int s2p_thin_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, int cin_real, void* ws, size_t ws_bytes, hipStream_t st);
+size_t s2p_thin_wgrad_ws_bytes(const s2p_conv_desc* d, int cin_real);
+size_t s2p_channel_sum_ws_bytes(int64_t pixels, int C);
+int s2p_channel_sum_det(int dtype, const void* dy, int64_t pixels, int C, int pitch, float* db, void* ws, size_t ws_bytes, void* stream);
 // row-streaming thin-Cout kernels (thin_rows.hip)
 bool s2p_thin_rows_applicable(const s2p_conv_desc* d);
 int s2p_thin_rows_fwd(const s2p_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int act,

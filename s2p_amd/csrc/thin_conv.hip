@@ -147,7 +147,8 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinArgs a) {
 static bool tiled_applicable(const s2p_conv_desc* d);
 int s2p_thin_tiled_fwd(const s2p_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int act,
                        float slope, hipStream_t st);
-int s2p_thin_tiled_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, int cin_real, hipStream_t st);
+int s2p_thin_tiled_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, int cin_real, void* ws, size_t ws_bytes, hipStream_t st);
+static int tiled_wgrad_blocks(const s2p_conv_desc* d);
 
 static void fill_args(ThinArgs& a, const s2p_conv_desc* d) {
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.x_pitch = d->x_pitch; a.Ho = d->Ho; a.Wo = d->Wo;
@@ -186,8 +187,15 @@ int s2p_thin_fwd(const s2p_conv_desc* d, const void* x, const void* w, const flo
   return 0;
 }
 
-int s2p_thin_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, int cin_real, hipStream_t st) {
-  if (tiled_applicable(d)) return s2p_thin_tiled_wgrad(d, x, dy, dw, cin_real, st);
+// scratch of the atomics-free form (tiled kernel only: per-workgroup partial tiles)
+size_t s2p_thin_wgrad_ws_bytes(const s2p_conv_desc* d, int cin_real) {
+  if (!tiled_applicable(d)) return 0;
+  return (size_t)tiled_wgrad_blocks(d) * d->Cout * d->KH * d->KW * cin_real * sizeof(float);
+}
+
+int s2p_thin_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, int cin_real, void* ws, size_t ws_bytes,
+                   hipStream_t st) {
+  if (tiled_applicable(d)) return s2p_thin_tiled_wgrad(d, x, dy, dw, cin_real, ws, ws_bytes, st);
   ThinArgs a{};
   fill_args(a, d);
   a.x = (const __bf16*)x; a.dy = (const __bf16*)dy; a.dw = dw; a.cin_real = cin_real;
@@ -218,6 +226,7 @@ struct TileArgs {
   int N, H, W, Cin, x_pitch, Ho, Wo, Cout, y_pitch, K, pad, reflect, act;
   float slope;
   int cin_real, tiles_x, tiles_y, ntiles;
+  float* part;                 // weight gradient: per-workgroup partial tiles [gridDim.x][Cout][T][cin_real] (nullptr: fp32 atomics)
 };
 
 // Halo tile -> LDS.  All global loads of a thread are issued before the first LDS store (up to MAXL 16-byte loads in
@@ -422,10 +431,28 @@ __global__ __launch_bounds__(512) void thin_tiled_wgrad_kernel(const TileArgs a)
         if (ci < a.cin_real)
 #pragma unroll
           for (int co = 0; co < 4; ++co)
-            if (co < a.Cout) atomicAdd(a.dw + ((size_t)co * T + t) * a.cin_real + ci, acc[i][co]);
+            if (co < a.Cout) {
+              const size_t o = ((size_t)co * T + t) * a.cin_real + ci;
+              if (a.part) a.part[(size_t)blockIdx.x * ((size_t)a.Cout * T * a.cin_real) + o] = acc[i][co];
+              else atomicAdd(a.dw + o, acc[i][co]);
+            }
       }
     }
   }
+}
+
+// dw[i] += sum over the workgroups' partial tiles, in workgroup order (bitwise reproducible)
+__global__ __launch_bounds__(256) void thin_tiled_wgrad_reduce_kernel(const float* part, int nblk, int n, float* dw) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = 0;
+  for (; b + 4 <= nblk; b += 4) {                       // four loads in flight; the additions keep one fixed order
+    const float v0 = part[(size_t)b * n + i], v1 = part[(size_t)(b + 1) * n + i], v2 = part[(size_t)(b + 2) * n + i], v3 = part[(size_t)(b + 3) * n + i];
+    s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+  }
+  for (; b < nblk; ++b) s0 += part[(size_t)b * n + i];
+  dw[i] += (s0 + s1) + (s2 + s3);
 }
 
 static bool tiled_applicable(const s2p_conv_desc* d) {
@@ -458,10 +485,19 @@ int s2p_thin_tiled_fwd(const s2p_conv_desc* d, const void* x, const void* w, con
   return 0;
 }
 
-int s2p_thin_tiled_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, int cin_real, hipStream_t st) {
+static int tiled_wgrad_blocks(const s2p_conv_desc* d) {
+  TileArgs a{};
+  fill_tile_args(a, d);
+  return a.ntiles < 512 ? a.ntiles : 512;
+}
+
+int s2p_thin_tiled_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, int cin_real, void* ws, size_t ws_bytes,
+                         hipStream_t st) {
   TileArgs a{};
   fill_tile_args(a, d);
   a.x = (const __bf16*)x; a.dy = (const __bf16*)dy; a.dw = dw; a.cin_real = cin_real;
+  const size_t need = s2p_thin_wgrad_ws_bytes(d, cin_real);
+  a.part = (ws && need > 0 && ws_bytes >= need) ? (float*)ws : nullptr;
   const int HW_ = TW + d->KH - 1, HH = TH + d->KH - 1;
   const size_t lds = (size_t)HW_ * HH * (d->Cin * 2 + 16) + 4 * TW * TH * 2;
   const int pairs = d->KH * d->KW * (d->Cin / 16);
@@ -472,5 +508,10 @@ int s2p_thin_tiled_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, 
   else if (pairs <= 8 * 25) hipLaunchKernelGGL(thin_tiled_wgrad_kernel<25>, dim3(blocks), dim3(512), lds, st, a);
   else hipLaunchKernelGGL(thin_tiled_wgrad_kernel<32>, dim3(blocks), dim3(512), lds, st, a);
   S2P_CHECK_LAUNCH("thin_tiled_wgrad_kernel");
+  if (a.part) {
+    const int n = d->Cout * d->KH * d->KW * cin_real;
+    hipLaunchKernelGGL(thin_tiled_wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, a.part, blocks, n, dw);
+    S2P_CHECK_LAUNCH("thin_tiled_wgrad_reduce_kernel");
+  }
   return 0;
 }

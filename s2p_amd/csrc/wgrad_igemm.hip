@@ -525,15 +525,34 @@ static bool wgrad_dma_plan(const s2p_conv_desc* d, int cin_real, int cout_real, 
   return true;
 }
 
-extern "C" size_t s2p_conv2d_wgrad_workspace(const s2p_conv_desc* d, int cin_real, int cout_real) {
-  if (!d || d->dtype != S2P_BF16 || d->KH * d->KW > 64) return 0;
-  if (s2p_thin_applicable(d) && cout_real == d->Cout) return 0;
+static inline size_t ws_align(size_t b) { return (b + 255) / 256 * 256; }
+// scratch of the K-split partial tiles of the LDS-DMA kernels (0: no split, or another kernel runs the layer)
+static size_t wgrad_dma_ws_bytes(const s2p_conv_desc* d, int cin_real, int cout_real, bool* dense_out) {
   WgradArgs a{};
-  bool dense;
+  bool dense = true;
   if (!wgrad_dma_plan(d, cin_real, cout_real, a, dense)) return 0;
+  if (dense_out) *dense_out = dense;
   if (a.splitk * a.groups <= 1) return 0;
   const size_t units = (size_t)a.splitk * a.groups;
   return units * a.part_rows * ((size_t)a.part_cols + 1) * sizeof(float);
+}
+// bias gradient as a separate channel-sum pass: its scratch sits behind the weight-gradient scratch
+static size_t wgrad_bias_ws_bytes(const s2p_conv_desc* d, int cout_real) {
+  return s2p_channel_sum_ws_bytes((int64_t)d->N * d->Ho * d->Wo, cout_real * d->groups);
+}
+
+extern "C" size_t s2p_conv2d_wgrad_workspace(const s2p_conv_desc* d, int cin_real, int cout_real) {
+  if (!d || d->dtype != S2P_BF16 || d->KH * d->KW > 64) return 0;
+  if (s2p_thin_applicable(d) && cout_real == d->Cout) {
+    const size_t t = s2p_thin_wgrad_ws_bytes(d, cin_real);
+    return t ? ws_align(t) + wgrad_bias_ws_bytes(d, cout_real) : 0;
+  }
+  bool dense = true;
+  WgradArgs a{};
+  if (!wgrad_dma_plan(d, cin_real, cout_real, a, dense)) return 0;
+  const size_t w = wgrad_dma_ws_bytes(d, cin_real, cout_real, nullptr);
+  if (dense) return w;                                   // fused bias gradient
+  return ws_align(w) + wgrad_bias_ws_bytes(d, cout_real);
 }
 
 extern "C" int s2p_conv2d_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, float* db,
@@ -555,8 +574,16 @@ extern "C" int s2p_conv2d_wgrad_ws(const s2p_conv_desc* d, const void* x, const 
   if (cout_pad > d->y_pitch) S2P_FAIL(-1, "s2p_conv2d_wgrad: dy pitch < padded Cout");
   if (db && d->transposed) S2P_FAIL(-1, "s2p_conv2d_wgrad: bias gradient is undefined for the transposed form");
   if (s2p_thin_applicable(d) && cout_real == d->Cout) {
-    if (db) { int rc = s2p_channel_sum(d->dtype, dy, (int64_t)d->N * d->Ho * d->Wo, cout_real, d->y_pitch, db, stream); if (rc) return rc; }
-    return s2p_thin_wgrad(d, x, dy, dw, cin_real, (hipStream_t)stream);
+    // with the scratch of s2p_conv2d_wgrad_workspace: per-workgroup partial tiles / partial channel sums + fixed-order
+    // reduces (no atomics); without it fp32 atomics
+    const size_t tw = s2p_thin_wgrad_ws_bytes(d, cin_real);
+    const bool det = tw > 0 && workspace && workspace_bytes >= s2p_conv2d_wgrad_workspace(d, cin_real, cout_real);
+    if (db) {
+      int rc = s2p_channel_sum_det(d->dtype, dy, (int64_t)d->N * d->Ho * d->Wo, cout_real, d->y_pitch, db,
+                                   det ? (char*)workspace + ws_align(tw) : nullptr, det ? wgrad_bias_ws_bytes(d, cout_real) : 0, stream);
+      if (rc) return rc;
+    }
+    return s2p_thin_wgrad(d, x, dy, dw, cin_real, det ? workspace : nullptr, det ? tw : 0, (hipStream_t)stream);
   }
   hipStream_t st = (hipStream_t)stream;
   {
@@ -579,14 +606,18 @@ extern "C" int s2p_conv2d_wgrad_ws(const s2p_conv_desc* d, const void* x, const 
       // they take the 2-stage DMA kernel without the fused bias accumulators (126 VGPRs, 32 KiB LDS: 4 workgroups per CU;
       // the 3-stage + fused-bias form is 146 VGPRs / 48 KiB = 3 per CU and measured 930 us on the 12-group gamma/beta
       // wgrad, the register-staged kernel 670 us, this form 521 us).  The bias gradient is a separate channel-sum pass.
+      const size_t wneed = wgrad_dma_ws_bytes(d, cin_real, cout_real, nullptr);
+      const size_t need = s2p_conv2d_wgrad_workspace(d, cin_real, cout_real);
+      const bool have_ws = workspace && need > 0 && workspace_bytes >= need;
       if (!dense && db) {
-        int rc = s2p_channel_sum(d->dtype, dy, (int64_t)d->N * d->Ho * d->Wo, cout_real * d->groups, d->y_pitch, db, stream);
+        int rc = s2p_channel_sum_det(d->dtype, dy, (int64_t)d->N * d->Ho * d->Wo, cout_real * d->groups, d->y_pitch, db,
+                                     have_ws ? (char*)workspace + ws_align(wneed) : nullptr, have_ws ? wgrad_bias_ws_bytes(d, cout_real) : 0,
+                                     stream);
         if (rc) return rc;
       }
       a.db = dense ? db : nullptr;              // dense: fused bias gradient (groups: db is [groups][Cout])
       const int units = a.groups * a.splitk;
-      const size_t need = s2p_conv2d_wgrad_workspace(d, cin_real, cout_real);
-      const bool det = units > 1 && workspace && workspace_bytes >= need && need > 0;
+      const bool det = units > 1 && have_ws && wneed > 0;
       if (det) {
         a.part = (float*)workspace;
         a.part_b = a.part + (size_t)units * a.part_rows * a.part_cols;
