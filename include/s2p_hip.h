@@ -95,8 +95,9 @@ int s2p_conv2d_dgrad_ws(const s2p_conv_desc* d, const void* dy, const void* w_bw
 int s2p_conv2d_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, float* db,
                      int cin_real, int cout_real, int64_t dw_gstride, int splitk, void* stream);
 /* The same with a caller-owned device scratch of at least s2p_conv2d_wgrad_workspace(...) bytes: the K-split units of the
- * bf16 kernels then store partial tiles there and a second kernel adds them to dw / db in a fixed order -- no atomics,
- * bitwise reproducible (s2p_conv2d_wgrad itself, and a NULL / short workspace, accumulate with fp32 atomics).            */
+ * bf16 kernels (and the workgroups of the thin tiled kernel, and the pixel blocks of a separate bias-gradient pass) then
+ * store partial tiles / sums there and a second kernel adds them to dw / db in a fixed order -- no atomics, bitwise
+ * reproducible (s2p_conv2d_wgrad itself, and a NULL / short workspace, accumulate with fp32 atomics).                    */
 size_t s2p_conv2d_wgrad_workspace(const s2p_conv_desc* d, int cin_real, int cout_real);
 int s2p_conv2d_wgrad_ws(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, float* db,
                         int cin_real, int cout_real, int64_t dw_gstride, int splitk, void* workspace,
