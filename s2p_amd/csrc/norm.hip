@@ -538,13 +538,6 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const T* dy, long long
     else if (c < C) atomicAdd(db + c, s);
   }
 }
-__global__ __launch_bounds__(256) void channel_sum_reduce_kernel(const float* part, int nblk, int Cs, int C, float* db) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += part[(size_t)b * Cs + c];
-  db[c] += s;
-}
 
 // ------------------------------------------------------------------------------------------------
 static int norm_check(const char* who, int dtype, int C, int p0, int p1, int p2) {
@@ -727,8 +720,8 @@ int s2p_channel_sum_det(int dtype, const void* dy, int64_t pixels, int C, int pi
                        (long long)pixels, C, pitch, db, rows, part);
   S2P_CHECK_LAUNCH("channel_sum_kernel");
   if (part) {
-    hipLaunchKernelGGL(channel_sum_reduce_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, part, nb, (int)grid.x * 64, C, db);
-    S2P_CHECK_LAUNCH("channel_sum_reduce_kernel");
+    s2p_partial_reduce(part, nb, (long long)grid.x * 64, C, db, (hipStream_t)stream);
+    S2P_CHECK_LAUNCH("s2p_partial_reduce_kernel(channel_sum)");
   }
   return 0;
 }

@@ -153,3 +153,33 @@ int s2p_head_fwd(const s2p_conv_desc* d, const void* x, const void* w, const flo
 int s2p_head_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, float* db, int cin_real,
                    void* workspace, size_t workspace_bytes, hipStream_t st);
 
+
+// out[i] += sum_b part[b * stride + i]  (b < nblk, i < n) in a FIXED order: wave w of the 16 adds the blocks w, w + 16, ...
+// (64 consecutive i per workgroup: coalesced), then wave 0 adds the 16 wave sums in wave order -- bitwise reproducible, and
+// the loads of a wave are independent (a single thread summing 200..500 partials one after the other took 40-50 us).
+static __global__ __launch_bounds__(1024) void s2p_partial_reduce_kernel(const float* part, int nblk, long long stride, int n, float* out) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (i < n) {
+    int b = w;
+    for (; b + 48 < nblk; b += 64) {                      // four loads in flight
+      const float v0 = part[(long long)b * stride + i], v1 = part[(long long)(b + 16) * stride + i];
+      const float v2 = part[(long long)(b + 32) * stride + i], v3 = part[(long long)(b + 48) * stride + i];
+      s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; b < nblk; b += 16) s += part[(long long)b * stride + i];
+  }
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][lane];
+    out[i] += t;
+  }
+}
+static inline void s2p_partial_reduce(const float* part, int nblk, long long stride, int n, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(s2p_partial_reduce_kernel, dim3(cdiv(n, 64)), dim3(1024), 0, st, part, nblk, stride, n, out);
+}

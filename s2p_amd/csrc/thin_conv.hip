@@ -441,20 +441,6 @@ __global__ __launch_bounds__(512) void thin_tiled_wgrad_kernel(const TileArgs a)
   }
 }
 
-// dw[i] += sum over the workgroups' partial tiles, in workgroup order (bitwise reproducible)
-__global__ __launch_bounds__(256) void thin_tiled_wgrad_reduce_kernel(const float* part, int nblk, int n, float* dw) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int b = 0;
-  for (; b + 4 <= nblk; b += 4) {                       // four loads in flight; the additions keep one fixed order
-    const float v0 = part[(size_t)b * n + i], v1 = part[(size_t)(b + 1) * n + i], v2 = part[(size_t)(b + 2) * n + i], v3 = part[(size_t)(b + 3) * n + i];
-    s0 += v0; s1 += v1; s2 += v2; s3 += v3;
-  }
-  for (; b < nblk; ++b) s0 += part[(size_t)b * n + i];
-  dw[i] += (s0 + s1) + (s2 + s3);
-}
-
 static bool tiled_applicable(const s2p_conv_desc* d) {
   if (!(d->dtype == S2P_BF16 && d->groups == 1 && !d->transposed && d->Cout <= 4 && d->stride == 1 && d->KH == d->KW &&
         d->KH >= 3 && d->KH <= 7 && d->Cin % 32 == 0 && d->Cin <= 128 && d->y_pitch == 8 && d->x_pitch == d->Cin))
@@ -510,8 +496,8 @@ int s2p_thin_tiled_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, 
   S2P_CHECK_LAUNCH("thin_tiled_wgrad_kernel");
   if (a.part) {
     const int n = d->Cout * d->KH * d->KW * cin_real;
-    hipLaunchKernelGGL(thin_tiled_wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, a.part, blocks, n, dw);
-    S2P_CHECK_LAUNCH("thin_tiled_wgrad_reduce_kernel");
+    s2p_partial_reduce(a.part, blocks, n, n, dw, st);          // dw += the workgroups' partial tiles, in a fixed order
+    S2P_CHECK_LAUNCH("s2p_partial_reduce_kernel(thin tiled wgrad)");
   }
   return 0;
 }
