@@ -508,16 +508,21 @@ template <typename T>
 __global__ __launch_bounds__(256) void channel_sum_kernel(const T* dy, long long pixels, int C, int pitch,
                                                           float* db, int rows_per_block, float* part) {
   constexpr int CE = DT<T>::CE;
-  constexpr int CS = 64, NCH = CS / CE, PR = 256 / NCH;
-  __shared__ float red[PR][CS + 1];
-  const int tid = threadIdx.x, cc = tid % NCH, pr = tid / NCH;
+  constexpr int CS = 64, NCH = CS / CE;
+  __shared__ float red[256][CE + 1];
+  const int tid = threadIdx.x;
+  // chunks of this 64-channel slab that hold real channels (a 3-channel image tensor has one): the threads are spread over
+  // (pixel row, chunk) so that thin tensors keep all 256 threads loading
+  int nch = (C - (int)blockIdx.x * CS + CE - 1) / CE; if (nch > NCH) nch = NCH;
+  int npow = 1; while (npow < nch) npow <<= 1;           // power of two: 256 / npow pixel rows per pass
+  const int cc = tid % npow, pr = tid / npow, PR = 256 / npow;
   const int c0 = blockIdx.x * CS + cc * CE;
   long long p0 = (long long)blockIdx.y * rows_per_block, p1 = p0 + rows_per_block;
   if (p1 > pixels) p1 = pixels;
   float q[CE];
 #pragma unroll
   for (int e = 0; e < CE; ++e) q[e] = 0.f;
-  if (c0 < C)
+  if (cc < nch)
     for (long long p = p0 + pr; p < p1; p += PR) {
       if (c0 + CE <= C) {
         Chunk<T> v; v.raw = *(const u32x4*)(dy + (size_t)p * pitch + c0);
@@ -528,11 +533,13 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const T* dy, long long
       }
     }
 #pragma unroll
-  for (int e = 0; e < CE; ++e) red[pr][cc * CE + e] = q[e];
+  for (int e = 0; e < CE; ++e) red[tid][e] = q[e];
   __syncthreads();
   if (tid < CS) {
+    const int ch = tid / CE, e = tid % CE;               // channel tid of the slab lives in chunk ch, element e
     float s = 0.f;
-    for (int i = 0; i < PR; ++i) s += red[i][tid];
+    if (ch < nch)
+      for (int i = 0; i < PR; ++i) s += red[i * npow + ch][e];
     int c = blockIdx.x * CS + tid;
     if (part) part[(size_t)blockIdx.y * (gridDim.x * CS) + c] = s;
     else if (c < C) atomicAdd(db + c, s);
