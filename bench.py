@@ -264,6 +264,32 @@ def main():
         dominant = dict(kind=dk, shape_N_H_W_Cin_Cout_k_stride_groups_transposed=list(dshape), launches_per_step=dv[2],
                         avg_launch_us=round(dv[1] * 1e3 / dv[2], 2), gflop_per_launch=round(dv[0] / dv[2] / 1e9, 2),
                         tflops=round(dv[0] / (dv[1] * 1e-3) / 1e12, 2), frac=round(dv[0] / (dv[1] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4))
+        # the dominant launch alone: 20 launches of the ResBlk conv captured in one hipGraph and replayed between two HIP events
+        # (no host launch gap inside the timed region: this is the figure rocprofv3's per-dispatch duration agrees with)
+        try:
+            lay = model.netG.lay["b0c0"]
+            hq = args.size // 4
+            xa = torch.randn(args.batch, hq, hq, 256, device=dev).to(model.netG.compute_dtype)
+            for _ in range(3):
+                lay.fwd(xa)
+            torch.cuda.synchronize()
+            gk = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gk):
+                for _ in range(20):
+                    lay.fwd(xa)
+            gk.replay(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                gk.replay()
+            e1.record(); torch.cuda.synchronize()
+            k_us = e0.elapsed_time(e1) * 1e3 / 100
+            k_fl = 2.0 * args.batch * hq * hq * 256 * 256 * 9
+            dominant["kernel_alone_us"] = round(k_us, 2)
+            dominant["kernel_alone_tflops"] = round(k_fl / (k_us * 1e-6) / 1e12, 1)
+            dominant["kernel_alone_frac"] = round(k_fl / (k_us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)
+        except Exception as e:      # the extra figure must never fail the bench
+            print("[bench] kernel-alone leg: %s" % str(e).splitlines()[0], file=sys.stderr)
         # HBM traffic of the dominant launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE in separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md): counters cannot be collected from
         # inside this process, so the latest committed measurement of the same kernel + grid is reported, with its source
