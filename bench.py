@@ -264,8 +264,9 @@ def main():
         dominant = dict(kind=dk, shape_N_H_W_Cin_Cout_k_stride_groups_transposed=list(dshape), launches_per_step=dv[2],
                         avg_launch_us=round(dv[1] * 1e3 / dv[2], 2), gflop_per_launch=round(dv[0] / dv[2] / 1e9, 2),
                         tflops=round(dv[0] / (dv[1] * 1e-3) / 1e12, 2), frac=round(dv[0] / (dv[1] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4))
-        # the dominant launch alone: 20 launches of the ResBlk conv captured in one hipGraph and replayed between two HIP events
-        # (no host launch gap inside the timed region: this is the figure rocprofv3's per-dispatch duration agrees with)
+        # the dominant launch alone and SUSTAINED: 20 launches of the ResBlk conv captured in one hipGraph, replayed 5 times between
+        # two HIP events (no host launch gap; back-to-back MFMA load, so the chip runs at its sustained MFMA clock: slower than
+        # the same launch between the HBM-bound norm kernels of the real step, which is what rocprofv3's per-dispatch time shows)
         try:
             lay = model.netG.lay["b0c0"]
             hq = args.size // 4
