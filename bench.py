@@ -268,6 +268,8 @@ def main():
         # two HIP events (no host launch gap; back-to-back MFMA load, so the chip runs at its sustained MFMA clock: slower than
         # the same launch between the HBM-bound norm kernels of the real step, which is what rocprofv3's per-dispatch time shows)
         try:
+            if world > 1:
+                raise RuntimeError("skipped with more than one rank (no extra graph capture beside a live RCCL group)")
             lay = model.netG.lay["b0c0"]
             hq = args.size // 4
             xa = torch.randn(args.batch, hq, hq, 256, device=dev).to(model.netG.compute_dtype)
@@ -275,7 +277,7 @@ def main():
                 lay.fwd(xa)
             torch.cuda.synchronize()
             gk = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gk):
+            with torch.cuda.graph(gk, capture_error_mode="relaxed"):
                 for _ in range(20):
                     lay.fwd(xa)
             gk.replay(); torch.cuda.synchronize()
