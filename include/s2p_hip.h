@@ -171,6 +171,12 @@ int s2p_in_norm_bwd(int dtype, const void* da, int da_pitch, const void* x, int 
                     const float* stats, const void* gb_img, int gb_pitch, const float* gb_st, int gb_st_pitch,
                     int act, float slope, float eps, float* sums, void* dx, int dx_pitch, void* dgb_img,
                     int dgb_pitch, float* dgb_st, int dgb_st_pitch, void* stream);
+/* The same with dx += res folded into the store (res: a tensor of dx's layout and dtype, e.g. the skip-connection gradient of
+ * a residual block; fp32 add, one rounding; the two-kernel path adds it in a third pass).                                   */
+int s2p_in_norm_bwd_res(int dtype, const void* da, int da_pitch, const void* x, int N, int HW, int C, int pitch,
+                        const float* stats, const void* gb_img, int gb_pitch, const float* gb_st, int gb_st_pitch,
+                        int act, float slope, float eps, float* sums, void* dx, int dx_pitch, void* dgb_img,
+                        int dgb_pitch, float* dgb_st, int dgb_st_pitch, const void* res, int res_pitch, void* stream);
 
 /* Small fp32 linear layers of the state path (replaces F.linear + LeakyReLU and their autograd backward for the
  * StateMapping MLP and the per-norm state affine; batch M of a few dozen rows: latency-bound, csrc/linear_small.hip).

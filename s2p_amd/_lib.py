@@ -71,6 +71,8 @@ SIGNATURES = {
                          c_float, c_float, _P, _P, c_int, _P, c_int, _P, c_int, _P],
     "s2p_in_norm_bwd": [c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, c_int,
                         c_float, c_float, _P, _P, c_int, _P, c_int, _P, c_int, _P],
+    "s2p_in_norm_bwd_res": [c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, c_int,
+                            c_float, c_float, _P, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P],
     "s2p_in_stats_floats": [c_int, c_int, c_int],
     "s2p_in_bwd_sums_floats": [c_int, c_int, c_int],
     "s2p_linear_fwd": [_P, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, c_float, _P, c_int, c_int, _P],

@@ -15,6 +15,7 @@
 struct NormArgs {
   const void* x; const void* da; const void* gb; const float* gbst; const float* stats; float* sums;
   void* y; void* dgb; float* dgbst;
+  const void* res; int res_pitch;   // fused backward only: dx += res (the ResBlk skip gradient), same dtype as dx
   int N, HW, C, x_pitch, da_pitch, gb_pitch, gbst_pitch, y_pitch, dgb_pitch, dgbst_pitch;
   int act; float slope, eps;
   int psplit, rows_per_split;       // geometry of THIS launch
@@ -493,6 +494,11 @@ __global__ __launch_bounds__(1024) void in_fused_bwd_kernel(const NormArgs a) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (a.res) {                                         // skip-connection gradient folded into the store (fp32 add, one rounding)
+      Chunk<T> rv; rv.raw = *(const u32x4*)((const T*)a.res + img * a.res_pitch + cb0 + (p * a.res_pitch + lc));
+#pragma unroll
+      for (int e = 0; e < CE; ++e) o0.set(e, o0.get(e) + rv.get(e));
+    }
     *(u32x4*)(yb + (p * a.y_pitch + lc)) = o0.raw;
     if (dgb) {
       *(u32x4*)(dgb + (p * a.dgb_pitch + lc)) = o1.raw;
@@ -669,7 +675,16 @@ extern "C" int s2p_in_norm_bwd(int dtype, const void* da, int da_pitch, const vo
                                const float* stats, const void* gb_img, int gb_pitch, const float* gb_st, int gb_st_pitch,
                                int act, float slope, float eps, float* sums, void* dx, int dx_pitch, void* dgb_img,
                                int dgb_pitch, float* dgb_st, int dgb_st_pitch, void* stream) {
+  return s2p_in_norm_bwd_res(dtype, da, da_pitch, x, N, HW, C, pitch, stats, gb_img, gb_pitch, gb_st, gb_st_pitch, act, slope, eps,
+                             sums, dx, dx_pitch, dgb_img, dgb_pitch, dgb_st, dgb_st_pitch, nullptr, 0, stream);
+}
+
+extern "C" int s2p_in_norm_bwd_res(int dtype, const void* da, int da_pitch, const void* x, int N, int HW, int C, int pitch,
+                                   const float* stats, const void* gb_img, int gb_pitch, const float* gb_st, int gb_st_pitch,
+                                   int act, float slope, float eps, float* sums, void* dx, int dx_pitch, void* dgb_img,
+                                   int dgb_pitch, float* dgb_st, int dgb_st_pitch, const void* res, int res_pitch, void* stream) {
   int rc = norm_check("s2p_in_norm_bwd", dtype, C, pitch, gb_pitch, da_pitch); if (rc) return rc;
+  if (res && (res_pitch != dx_pitch || dx_pitch != C)) S2P_FAIL(-1, "s2p_in_norm_bwd_res: res must have the layout of dx (pitch == C)");
   const int maxhw = dtype == S2P_F32 ? 256 : 512;
   const bool simple_act = act == S2P_ACT_NONE || act == S2P_ACT_RELU || act == S2P_ACT_LRELU;
   if (HW > maxhw || !simple_act || s2p_env_set("S2P_NO_FUSED_NORM")) {
@@ -677,8 +692,10 @@ extern "C" int s2p_in_norm_bwd(int dtype, const void* da, int da_pitch, const vo
     rc = s2p_in_bwd_reduce(dtype, da, da_pitch, x, N, HW, C, pitch, stats, gb_img, gb_pitch, gb_st, gb_st_pitch, act, slope, eps,
                            sums, stream);
     if (rc) return rc;
-    return s2p_in_bwd_apply(dtype, da, da_pitch, x, N, HW, C, pitch, stats, gb_img, gb_pitch, gb_st, gb_st_pitch, act, slope, eps,
-                            sums, dx, dx_pitch, dgb_img, dgb_pitch, dgb_st, dgb_st_pitch, stream);
+    rc = s2p_in_bwd_apply(dtype, da, da_pitch, x, N, HW, C, pitch, stats, gb_img, gb_pitch, gb_st, gb_st_pitch, act, slope, eps,
+                          sums, dx, dx_pitch, dgb_img, dgb_pitch, dgb_st, dgb_st_pitch, stream);
+    if (rc || !res) return rc;
+    return s2p_add(dtype, dx, res, dx, (int64_t)N * HW * C, stream);          // two-kernel path: the residual is a third pass
   }
   if (dx_pitch % (dtype == S2P_F32 ? 4 : 8) || dgb_pitch % (dtype == S2P_F32 ? 4 : 8))
     S2P_FAIL(-1, "s2p_in_norm_bwd: bad output pitch");
@@ -687,6 +704,7 @@ extern "C" int s2p_in_norm_bwd(int dtype, const void* da, int da_pitch, const vo
   a.y = dx; a.dgb = dgb_img; a.dgbst = dgb_st; a.dgbst_pitch = dgb_st_pitch;
   a.N = N; a.HW = HW; a.C = C; a.x_pitch = pitch; a.da_pitch = da_pitch; a.gb_pitch = gb_pitch;
   a.gbst_pitch = gb_st_pitch; a.y_pitch = dx_pitch; a.dgb_pitch = dgb_pitch; a.act = act; a.slope = slope; a.eps = eps;
+  a.res = res; a.res_pitch = res_pitch;
   const bool half = s2p_env_set("S2P_NORM_CS32") && C % 32 == 0;
   dim3 grid(N, cdiv(C, half ? 32 : 64));
   hipStream_t st = (hipStream_t)stream;

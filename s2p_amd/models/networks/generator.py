@@ -25,6 +25,7 @@ WGRAD_SIDE = True        # deferred weight gradients on a side stream (A/B: tool
 WGRAD_CHUNK_BLOCKS = 2   # ... launched every this many finished ResBlks, under the rest of the backward chain (0: one batch behind it)
 STATE_SIDE_FWD = True    # state path on its side stream in the forward / in the backward (diagnostic switches)
 STATE_SIDE_BWD = True
+FUSE_SKIP_ADD = True     # ResBlk backward: the skip gradient is added inside the MAT backward launch (s2p_in_norm_bwd_res)
 COND_SIDE = True         # backward of the image-conditioning branch on its own stream, concurrent with the encoder backward
 
 
@@ -340,8 +341,11 @@ class S2PGenerator(BaseNetwork):
             d_c0 = ops.in_bwd(d_nB, c0, C, sB, gb_all, o1, st_all, o1, ACT_LRELU, LRELU, dgb_all, o1, dst_all, o1)
             wjobs.append((L[f"b{b}c0"], nA, d_c0))
             d_nA = L[f"b{b}c0"].dgrad(d_c0, nA.shape)
-            d_xb = ops.in_bwd(d_nA, x, C, sA, gb_all, o0, st_all, o0, ACT_LRELU, LRELU, dgb_all, o0, dst_all, o0)
-            dx = ops.add(dx, d_xb, out=d_xb)
+            if FUSE_SKIP_ADD:       # the skip-connection gradient dx is added in the same launch: no separate add pass
+                dx = ops.in_bwd(d_nA, x, C, sA, gb_all, o0, st_all, o0, ACT_LRELU, LRELU, dgb_all, o0, dst_all, o0, res=dx)
+            else:
+                d_xb = ops.in_bwd(d_nA, x, C, sA, gb_all, o0, st_all, o0, ACT_LRELU, LRELU, dgb_all, o0, dst_all, o0)
+                dx = ops.add(dx, d_xb, out=d_xb)
             if ws is not None and WGRAD_CHUNK_BLOCKS > 0 and (k + 1) % WGRAD_CHUNK_BLOCKS == 0 and k + 1 < self.n_blocks:
                 side_wgrads(wjobs)
                 wjobs = []

@@ -236,9 +236,10 @@ def in_norm_fwd(x, C, gb=None, gb_off=0, gb_st=None, st_off=0, act=ACT_NONE, slo
 
 
 def in_bwd(da, x, C, stats, gb=None, gb_off=0, gb_st=None, st_off=0, act=ACT_NONE, slope=0.2, dgb=None, dgb_off=0,
-           dgb_st=None, dst_off=0):
+           dgb_st=None, dst_off=0, res=None):
     """Backward of in_apply_fwd.  Returns dx; writes d(gamma_img|beta_img) into dgb at channel offset dgb_off and
-    d(gamma_st|beta_st) into the fp32 [N, pitch] tensor dgb_st at column offset dst_off (layout of gb_st)."""
+    d(gamma_st|beta_st) into the fp32 [N, pitch] tensor dgb_st at column offset dst_off (layout of gb_st).
+    res: optional [N,H,W,C] tensor added to dx in the same launch (the skip-connection gradient of a residual block)."""
     N, H, W, xp = x.shape
     sums = torch.empty(lib().s2p_in_bwd_sums_floats(N, H * W, C), dtype=torch.float32, device=x.device)
     gbp, gb_pitch, stp, st_pitch = _gb_args(gb, gb_off, gb_st, st_off)
@@ -251,10 +252,13 @@ def in_bwd(da, x, C, stats, gb=None, gb_off=0, gb_st=None, st_off=0, act=ACT_NON
     dstp = dgb_st.data_ptr() + dst_off * 4 if dgb_st is not None else None
     _ = ptr(dgb), ptr(dgb_st)
     # one fused launch for small planes, the reduce + apply pair otherwise (s2p_in_norm_bwd decides)
-    check(lib().s2p_in_norm_bwd(dt, ptr(da), da.shape[3], ptr(x), N, H * W, C, xp, ptr(stats), gbp, gb_pitch, stp,
-                                st_pitch, act, slope, IN_EPS, ptr(sums), ptr(dx), C, dgbp,
-                                dgb.shape[3] if dgb is not None else 0, dstp,
-                                dgb_st.shape[1] if dgb_st is not None else 0, stream()), "s2p_in_norm_bwd")
+    if res is not None:
+        assert res.shape == dx.shape and res.dtype == dx.dtype and res.is_contiguous()
+    check(lib().s2p_in_norm_bwd_res(dt, ptr(da), da.shape[3], ptr(x), N, H * W, C, xp, ptr(stats), gbp, gb_pitch, stp,
+                                    st_pitch, act, slope, IN_EPS, ptr(sums), ptr(dx), C, dgbp,
+                                    dgb.shape[3] if dgb is not None else 0, dstp,
+                                    dgb_st.shape[1] if dgb_st is not None else 0, ptr(res), C if res is not None else 0,
+                                    stream()), "s2p_in_norm_bwd")
     pr.done()
     return dx
 

@@ -589,3 +589,22 @@ def test_linear_small_fwd_bwd(hip_device, case):
     assert rel_err(dx[:, :K], xr.grad) < 1e-5 and float(dx[:, K:].abs().max() if Kp > K else 0.0) == 0.0
     dw2, db2, dx2 = run()
     assert torch.equal(dw, dw2) and torch.equal(db, db2) and torch.equal(dx, dx2)
+
+
+@pytest.mark.parametrize("dtype,HW", [(torch.bfloat16, 21), (torch.float32, 9), (torch.bfloat16, 40)])
+def test_instance_norm_backward_with_fused_residual(hip_device, dtype, HW):
+    """s2p_in_norm_bwd_res: dx + res in one launch must equal the two-launch form (backward, then add) to one rounding, on the
+    fused small-plane kernel (21x21, 9x9) and on the two-kernel path (40x40: the residual is a third pass there)."""
+    dev = hip_device
+    g = torch.Generator().manual_seed(3)
+    N, C = 3, 128
+    x = (torch.randn(N, HW, HW, C, generator=g) * 1.5 + 0.3).to(dtype).to(dev)
+    da = torch.randn(N, HW, HW, C, generator=g).to(dtype).to(dev)
+    res = torch.randn(N, HW, HW, C, generator=g).to(dtype).to(dev)
+    y, stats = ops.in_norm_fwd(x, C, act=ACT_LRELU, slope=0.2)
+    dx0 = ops.in_bwd(da, x, C, stats, act=ACT_LRELU, slope=0.2)
+    dx1 = ops.in_bwd(da, x, C, stats, act=ACT_LRELU, slope=0.2, res=res)
+    ref = dx0.float() + res.float()
+    tol = 1e-6 if dtype == torch.float32 else 1.6e-2          # bf16: dx0 was rounded once before the add, dx1 only after it
+    err = float((dx1.float() - ref).abs().max() / ref.abs().max())
+    assert err < tol, err
