@@ -44,10 +44,9 @@ def main(args=None):
                             static[k].copy_(data[k], non_blocking=True)
                     sg = StepGraph()
                     trainer.seg = sg
-                    sg.capture(train_step)                 # runs the step once for real while capturing
+                    sg.capture(train_step)                 # kernels are only RECORDED during capture ...
                     captured_lr = trainer.old_lr
-                else:
-                    sg.replay()
+                sg.replay()                                # ... so the batch is trained on by the replay, also right after a capture
             else:
                 if i % opt.D_steps_per_G == 0:
                     trainer.run_generator_one_step(data)
