@@ -8,8 +8,8 @@ set -e
 cd "$(dirname "$0")"
 OUT=libs2p_hip.so; SUF=""; EXTRA=""
 if [ "$1" = "diag" ]; then OUT=libs2p_hip_diag.so; SUF=".diag"; EXTRA="-DS2P_DIAG_BUILD"; shift; fi
-SRCS="conv_igemm.hip wgrad_igemm.hip wgrad_slab.hip wgrad_head.hip linear_small.hip norm.hip misc.hip thin_conv.hip thin_rows.hip metrics.hip"
-newest=$(ls -t $SRCS s2p_common.h ../../include/s2p_hip.h build.sh | head -1)
+SRCS="conv_igemm.hip conv_plane.hip wgrad_igemm.hip wgrad_slab.hip wgrad_head.hip linear_small.hip norm.hip misc.hip thin_conv.hip thin_rows.hip metrics.hip"
+newest=$(ls -t $SRCS s2p_common.h conv_plane.h ../../include/s2p_hip.h build.sh | head -1)
 if [ -z "$FORCE" ] && [ -f "$OUT" ] && [ "$OUT" -nt "$newest" ]; then echo "up to date: $(pwd)/$OUT"; exit 0; fi
 pids=(); objs=""
 for s in $SRCS; do

@@ -12,6 +12,7 @@
 // padded to 80 B (conflict-free ds_read_b128); global->register->LDS staging, double buffered, one barrier
 // per K step; epilogue goes through LDS so every global store is a full 16-B chunk along the channel axis.
 #include "s2p_common.h"
+#include "conv_plane.h"
 #include <type_traits>
 
 #define MAX_TAPS 64
@@ -1236,6 +1237,33 @@ static int launch_fast(GatherArgs& a, int groups, hipStream_t st) {
   if (!no_dma && !no_split && groups == 1 && a.nphase == 0 && a.ostride == 1 && a.oy0 == 0 && a.ox0 == 0 && a.Qh == a.Ho &&
       a.Qw == a.Wo && (a.plan || a.ws))
     S_plan = conv_split_plan((int)grid.x, a.Ktot / 64);
+  // small planes (21x21 ResBlk / VGG conv3 / gamma-beta layers and their dgrads): one workgroup per (image, 64-channel slab),
+  // the whole padded plane resident in LDS (conv_plane.hip)
+  static const int no_plane = s2p_env_set("S2P_NO_PLANE");          // A/B switch (diagnostics build only)
+  if (!no_plane && !no_dma && a.nphase == 0 && a.T == 9 && a.istride == 1 && a.ostride == 1 && a.oy0 == 0 && a.ox0 == 0 &&
+      a.Qh == a.Hi && a.Qw == a.Wi && a.Ho == a.Qh && a.Wo == a.Qw && a.M % (a.Qh * a.Qw) == 0) {
+    PlaneArgs p{};
+    bool ok = true;
+    for (int t = 0; t < 9; ++t) p.wt[t] = -1;
+    for (int t = 0; t < 9 && ok; ++t) {
+      const int dy = (int)(signed char)(a.tap[t] & 0xff), dx = (int)(signed char)((a.tap[t] >> 8) & 0xff);
+      if (dy < -1 || dy > 1 || dx < -1 || dx > 1 || p.wt[(dy + 1) * 3 + dx + 1] >= 0) ok = false;
+      else p.wt[(dy + 1) * 3 + dx + 1] = a.tap[t] >> 16;
+    }
+    if (ok) {
+      p.x = a.x; p.w = a.w; p.bias = a.bias; p.aux = a.aux; p.aux2 = a.aux2; p.y = a.y;
+      p.N = a.M / (a.Qh * a.Qw); p.H = a.Qh; p.W = a.Qw;
+      p.Cin = a.Cin; p.x_pitch = a.x_pitch; p.x_gstride = a.x_gstride;
+      p.Cout = a.Cout; p.Cst = a.Cst; p.y_pitch = a.y_pitch; p.y_gstride = a.y_gstride;
+      p.w_row = a.w_row; p.w_gstride = a.w_gstride;
+      p.act = a.act; p.epi = a.epi; p.gact = a.gact; p.slope = a.slope; p.gslope = a.gslope;
+      p.x_bytes = a.x_bytes; p.w_bytes = a.w_bytes;
+      if (s2p_conv_plane_applicable(p)) {
+        if (a.plan) return 0;                              // no scratch
+        return s2p_conv_plane_launch(p, groups, st);
+      }
+    }
+  }
   if constexpr (BCO == 128 && BPIX == 128) {
     if (S_plan <= 1 && !no_dma && !no_halo && a.istride == 1 && a.ostride == 1 && a.Qh == a.Hi && a.Qw == a.Wi && a.Ho == a.Qh &&
         a.Wo == a.Qw && a.T >= 4) {

@@ -1,0 +1,21 @@
+// Plane-resident 3x3 "same" convolution (conv_plane.hip): host-side argument block + entry points.
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct PlaneArgs {
+  const void* x; const void* w; const float* bias; const void* aux; const void* aux2; void* y;
+  int N, H, W;                       // output grid == input grid (stride 1, pad 1)
+  int Cin, x_pitch, x_gstride;       // per-group input channels (multiple of 64), tensor pitch, channels between groups
+  int Cout, Cst, y_pitch, y_gstride;
+  int w_row;                         // elements per packed weight row ([Cout][tap][Cin])
+  long long w_gstride;
+  int wt[9];                         // packed-weight tap index of the geometric tap (dy+1)*3 + (dx+1)
+  int act, epi, gact;
+  float slope, gslope;
+  unsigned x_bytes, w_bytes;
+  int nco;                           // set by the launcher: Cout / 64
+  int diag;                          // timing ablations (diagnostics build only)
+};
+
+bool s2p_conv_plane_applicable(const PlaneArgs& a);
+int s2p_conv_plane_launch(PlaneArgs& a, int groups, hipStream_t st);

@@ -1,0 +1,391 @@
+// Plane-resident 3x3 "same" convolution for small feature maps (the 21x21 ResBlk / VGG conv3 / gamma-beta layers and their
+// stride-1 dgrads), bf16, NHWC, gfx950.
+//
+// Decomposition: ONE workgroup = one image x one 64-channel slab of the output (N * Cout/64 workgroups: 256 for the
+// 64 x 256-channel ResBlk conv = one per CU, no tile quantisation) and it keeps the image's WHOLE zero-padded input plane
+// of the current 32-channel half-slab in LDS:
+//   * the plane is stored on a padded raster, position p(y,x) = (y+1)*WP + x + 1 with one zero column per row and a zero
+//     row above / below, so a tap (dy,dx) is the constant position shift dy*WP + dx -- no validity masks, no per-tap
+//     address arithmetic: every fragment read is  base_register + immediate;
+//   * LDS images are [16-ch pair][position or co][2 x 16 B]: 32-byte rows.  For a 16-lane group of ds_read_b128 (8 rows
+//     at k-chunk q, 8 rows at q+1: the v_mfma_f32_16x16x32_bf16 operand map) consecutive rows then fall on 16 distinct
+//     16-B slots for ANY start row, i.e. the reads are conflict-free at every tap shift without an XOR swizzle;
+//   * 8 waves = 2 per SIMD.  Waves w and w+4 own the SAME 64 co x 112 px output tile (28 accumulator tiles of 16x16) and
+//     split K: wave set 0 takes the even K steps (one step = one tap x 32 channels = 28 MFMAs), set 1 the odd ones, so one
+//     wave's LDS-DMA issue, fragment reads and barrier wait run under its partner's MFMAs; the two partial accumulators are
+//     added through LDS once, after the loop.  One s_barrier per PAIR of K steps (~900 MFMA cycles per SIMD);
+//   * weights stream through a 6-stage ring of 4-KiB stages (one stage = one K step), two pair-steps ahead, by LDS-DMA
+//     (buffer_load ... lds) with counted vmcnt; the next half-slab's plane is fetched while the current one is swept.
+// Per workgroup and K step the LDS carries 11 KiB of fragment reads for 28 MFMAs (the 128x128-tile kernels: 16 KiB for
+// 16 larger MFMAs of twice the cycles) and 4 KiB of weight writes for 448 px (there: 16 KiB for 128 px).
+#include "s2p_common.h"
+#include "conv_plane.h"
+#include <type_traits>
+
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+
+template <int B, int E, typename F>
+__device__ __forceinline__ void pl_static_for(F&& f) {
+  if constexpr (B < E) { f(std::integral_constant<int, B>{}); pl_static_for<B + 1, E>(f); }
+}
+
+// DMA with the uniform part of the source offset in an SGPR (soffset); the range check uses voffset only, so an invalid
+// lane (voffset >= num_records) still returns zeros.
+__device__ __forceinline__ void pl_dma16(i32x4 rsrc, unsigned lds_dst, int voffset, int soffset) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
+               :: "v"(voffset), "s"(rsrc), "s"(lds_dst), "s"(soffset) : "memory");
+}
+
+namespace {
+constexpr int PL_NPOS = 512;                 // padded-raster positions per plane buffer
+constexpr int PL_CPS = PL_NPOS * 32;         // bytes between the two 16-channel pairs of a half-slab
+constexpr int PL_PBUF = 2 * PL_CPS;          // one half-slab plane buffer (32 KiB)
+constexpr int PL_WST = 4096;                 // one weight stage: [2 pairs][64 co][32 B]
+constexpr int PL_RING = 6;
+constexpr int PL_ERS = 144;                  // epilogue staging row: 64 co x 2 B + 16
+}
+
+// DIAG: timing ablations, instantiated only in the diagnostics build; a bit mask: 1 no in-loop DMA, 2 no MFMAs, 4 no fragment
+// reads, 8 no K loop, 16 whole-loop clock stamps, 32 per-segment stamps (waves 0 and 4); outputs are invalid for DIAG != 0.
+template <int PB, int WP, int DIAG>
+__global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
+  typedef __bf16 T;
+  constexpr int BPIX = 4 * PB * 16;
+  constexpr int NT = 4 * PB;                                   // accumulator tiles per wave
+  constexpr int MERGE = 4 * NT * 1024;
+  constexpr int MAIN = 2 * PL_PBUF + PL_RING * PL_WST;
+  constexpr int EPI = BPIX * PL_ERS;
+  constexpr int SMEM = MERGE > MAIN ? (MERGE > EPI ? MERGE : EPI) : (MAIN > EPI ? MAIN : EPI);
+  __shared__ __attribute__((aligned(1024))) char smem[SMEM];
+  char* const pbase = smem;
+  char* const wbase = smem + 2 * PL_PBUF;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int set = wave >> 2, wq = wave & 3;
+  const int q = lane >> 4, l15 = lane & 15;
+  const int g = blockIdx.y;
+  // workgroup -> (image, co slab): the nco slabs of one image run back to back on ONE XCD (blocks b, b+8, ... share an
+  // XCD under the observed round-robin placement: speed only), so the image's plane comes from HBM once per XCD.
+  int img, cs;
+  {
+    const int bid = blockIdx.x, nco = a.nco;
+    if ((a.N & 7) == 0) { const int xcd = bid & 7, k = bid >> 3; cs = k % nco; img = (k / nco) * 8 + xcd; }
+    else { cs = bid % nco; img = bid / nco; }
+  }
+  const int co_base = cs * 64;
+  const int HW = a.H * a.W;
+
+  const T* xg = (const T*)a.x + (size_t)g * a.x_gstride;
+  const T* wg = (const T*)a.w + (size_t)g * a.w_gstride;
+  const i32x4 xrs = s2p_make_rsrc(xg, a.x_bytes - (unsigned)g * (unsigned)a.x_gstride * 2u);
+  const i32x4 wrs = s2p_make_rsrc(wg, a.w_bytes);
+  const unsigned p_lds = __builtin_amdgcn_readfirstlane(s2p_lds_addr(pbase));
+  const unsigned w_lds = __builtin_amdgcn_readfirstlane(s2p_lds_addr(wbase));
+  const unsigned OOB = 0x80000000u;
+
+  // ---- fragment read bases --------------------------------------------------------------------------------------
+  int bB[PB];
+#pragma unroll
+  for (int j = 0; j < PB; ++j) {
+    int m = (wq * PB + j) * 16 + l15;
+    if (m >= HW) m = HW - 1;                                   // padding columns of the last block: computed, never stored
+    const int y = m / a.W, x = m - y * a.W;
+    bB[j] = (q >> 1) * PL_CPS + (q & 1) * 16 + (y * WP + x) * 32;
+  }
+  const int bA = (q >> 1) * 2048 + l15 * 32 + (q & 1) * 16;
+
+  // ---- DMA source offsets ---------------------------------------------------------------------------------------
+  // plane: 32 pieces per half-slab (piece = 32 positions x one 16-channel pair); wave w issues pieces w, w+8, w+16, w+24
+  int hv[4]; unsigned hdst[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int ii = wave + 8 * k;
+    const int cp = ii & 1, pg = ii >> 1;
+    const int pos = 32 * pg + (lane >> 1);
+    const int pm = pos - 1;
+    const int yy = pm / WP - 1, xx = pm % WP;
+    const bool ok = pos >= 1 && yy >= 0 && yy < a.H && xx < a.W;
+    hv[k] = ok ? (int)((((unsigned)(img * a.H + yy) * a.W + xx) * a.x_pitch) * 2u + (2 * cp + (lane & 1)) * 16) : (int)OOB;
+    hdst[k] = (unsigned)(cp * PL_CPS + pg * 1024);
+    if constexpr ((DIAG & 64) != 0) hv[k] = (int)(((unsigned)img * a.H * a.W * a.x_pitch) * 2u + ii * 1024 + lane * 16);   // timing only: coalesced source
+  }
+  // weights: 4 pieces per stage (piece = 32 co x one pair); wave w issues piece (w & 3) of the stage its set consumes
+  int wv; unsigned wdst;
+  {
+    const int cp = wave & 1, cohalf = (wave >> 1) & 1;
+    const int co = co_base + 32 * cohalf + (lane >> 1);
+    wv = co < a.Cout ? (int)((unsigned)co * a.w_row * 2u + (2 * cp + (lane & 1)) * 16) : (int)OOB;
+    wdst = (unsigned)(cp * 2048 + cohalf * 1024);
+    if constexpr ((DIAG & 64) != 0) wv = (int)((unsigned)co_base * a.w_row * 2u + (wave & 3) * 1024 + lane * 16);            // timing only: coalesced source
+  }
+  int wto[9];                                                   // byte offset of geometric tap t inside a packed weight row
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wto[t] = a.wt[t] * a.Cin * 2;
+
+  const int nhs = a.Cin / 32;                                   // half-slabs (host guarantees Cin % 64 == 0)
+  auto issue_plane2 = [&](int buf, int hs, int k0) {            // two of this wave's four pieces of half-slab hs
+    const int so = hs * 64;
+#pragma unroll
+    for (int k = k0; k < k0 + 2; ++k)
+      pl_dma16(xrs, p_lds + (unsigned)(buf * PL_PBUF) + hdst[k], hs < nhs ? hv[k] : (int)OOB, so);
+  };
+  auto issue_w = [&](int stage, int tap_off, int hs) {
+    pl_dma16(wrs, w_lds + (unsigned)(stage * PL_WST) + wdst, hs < nhs ? wv : (int)OOB, tap_off + hs * 64);
+  };
+
+  f32x4v acc[4][PB];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < PB; ++j) acc[i][j] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: plane of half-slab 0 + the first weight stages ----------------------------------------------------
+  issue_plane2(0, 0, 0);
+  issue_plane2(0, 0, 2);
+  // The two wave sets run the SAME pair-step half a period apart, so that one wave of a SIMD issues MFMAs while its partner
+  // issues DMA, reads fragments and waits (MI355X_MICROARCH.md, "Two waves per SIMD", items 1 and 9): after the barrier
+  //   set 0:  DMA, fragment reads of its step, 28 MFMAs;
+  //   set 1:  28 MFMAs on the fragments it read BEFORE the barrier, then DMA and the fragment reads of its next step.
+  // Set 1 therefore reads a stage one barrier earlier and keeps its weights three pair-steps ahead (set 0: two); set 0
+  // owns the even ring stages, set 1 the odd ones.
+  auto read_frags = [&](auto uc, bf16x8 (&fa)[4], bf16x8 (&fb)[PB]) {
+    constexpr int u = decltype(uc)::value % 18;
+    constexpr int t = u % 9, hsl = u / 9, stage = u % PL_RING;
+    const char* wp = wbase + stage * PL_WST + bA;
+    const char* pp = pbase + hsl * PL_PBUF + ((t / 3) * WP + (t % 3)) * 32;
+    if constexpr ((DIAG & 4) != 0) {                      // timing ablation: no fragment reads (lane-dependent junk operands)
+      const bf16x8 junk = __builtin_bit_cast(bf16x8, (u32x4){(unsigned)bA * 2654435761u, 0x3f80bf80u, 0x3f803f80u, (unsigned)lane * 97u + 0x3f000000u});
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = junk;
+#pragma unroll
+      for (int j = 0; j < PB; ++j) fb[j] = junk;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = *(const bf16x8*)(wp + i * 512);
+#pragma unroll
+      for (int j = 0; j < PB; ++j) fb[j] = *(const bf16x8*)(pp + bB[j]);
+    }
+  };
+  auto mfmas = [&](bf16x8 (&fa)[4], bf16x8 (&fb)[PB]) {
+    if constexpr ((DIAG & 2) != 0) {                                  // timing ablation: no MFMAs (the reads stay live)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(fa[i]));
+#pragma unroll
+      for (int j = 0; j < PB; ++j) asm volatile("" :: "v"(fb[j]));
+    } else {
+#pragma unroll
+      for (int j = 0; j < PB; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  // what every wave issues in pair-step U: one weight piece (AHEAD K steps ahead of its own step u) + its share of the next planes
+  auto issue_dma = [&](auto Uc, auto uc, auto aheadc, int k2) {
+    constexpr int U = decltype(Uc)::value, u2 = decltype(uc)::value + decltype(aheadc)::value;
+    if constexpr ((DIAG & 1) == 0) {
+      issue_w(u2 % PL_RING, wto[u2 % 9], k2 + u2 / 9);
+      if constexpr (U == 0) issue_plane2(1, k2 + 1, 0);         // buffer 1 was last read in pair-step 8 of the previous iteration
+      if constexpr (U == 1) issue_plane2(1, k2 + 1, 2);
+      if constexpr (U == 5) issue_plane2(0, k2 + 2, 0);         // buffer 0 was last read in pair-step 4
+      if constexpr (U == 6) issue_plane2(0, k2 + 2, 2);
+    }
+  };
+  // top of pair-step U: everything this wave issued before the previous pair-step has landed (what it issued IN the previous
+  // pair-step -- one weight piece, plus two plane pieces after U = 0, 1, 5, 6 -- may still be in flight), its own LDS
+  // reads have returned (another wave's DMA may overwrite what they read after the barrier), then the workgroup barrier
+  auto sync_top = [&](auto Uc) {
+    constexpr int UP = (decltype(Uc)::value + 8) % 9;
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (UP == 0 || UP == 1 || UP == 5 || UP == 6) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  const int nloop = (DIAG & 8) ? 0 : nhs;
+  unsigned long long seg[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;  // DIAG & 32: cycles per loop segment, summed over the loop
+  auto stamp = [&](int k) {
+    if constexpr ((DIAG & 32) != 0) {
+      unsigned long long t;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (k >= 0) seg[k] += t - tprev;
+      tprev = t;
+    }
+  };
+  unsigned long long st_c0 = 0, st_r0 = 0;                      // DIAG 6: shader-clock / 100 MHz stamps around the K loop -> y (output invalid)
+  if constexpr ((DIAG & 48) != 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+  if (set == 0) {
+    issue_w(0, wto[0], 0);
+    issue_w(2, wto[2], 0);
+    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");            // (the barrier set 1 needs before its first fragment reads)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    stamp(-1);
+    for (int k2 = 0; k2 < nloop; k2 += 2) {                     // two half-slabs = 18 K steps = 9 pair-steps per iteration
+      pl_static_for<0, 9>([&](auto Uc) {
+        constexpr int U = decltype(Uc)::value;
+        typedef std::integral_constant<int, 2 * U> uc;
+        stamp(3);                                               // [3] top wait (vmcnt / lgkmcnt)
+        sync_top(Uc);
+        stamp(4);                                               // [4] barrier
+        bf16x8 fa[4], fb[PB];
+        read_frags(uc{}, fa, fb);                               // reads first: their latency runs under the DMA issue below
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(0);                                               // [0] fragment reads, issue to data
+        issue_dma(Uc, uc{}, std::integral_constant<int, 4>{}, k2);
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(1);                                               // [1] DMA issue
+        mfmas(fa, fb);
+        stamp(2);                                               // [2] MFMA issue
+      });
+    }
+  } else {
+    issue_w(1, wto[1], 0);
+    issue_w(3, wto[3], 0);
+    issue_w(5, wto[5], 0);
+    bf16x8 fa[4], fb[PB];
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");            // plane 0 and the stage of step 1 (all waves: barrier below)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(std::integral_constant<int, 1>{}, fa, fb);
+    stamp(-1);
+    for (int k2 = 0; k2 < nloop; k2 += 2) {
+      pl_static_for<0, 9>([&](auto Uc) {
+        constexpr int U = decltype(Uc)::value;
+        typedef std::integral_constant<int, 2 * U + 1> uc;
+        stamp(3);
+        sync_top(Uc);
+        stamp(4);
+        mfmas(fa, fb);
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(2);
+        read_frags(std::integral_constant<int, 2 * U + 3>{}, fa, fb);
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(0);
+        issue_dma(Uc, uc{}, std::integral_constant<int, 6>{}, k2);
+        stamp(1);
+      });
+    }
+  }
+  S2P_WAIT_VMCNT(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  if constexpr ((DIAG & 48) != 0) {
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0 && (wave & 3) == 0 && g == 0) {                // waves 0 (set 0) and 4 (set 1): 8 words each
+      unsigned long long* o = (unsigned long long*)a.y + ((size_t)blockIdx.x * 2 + set) * 8;
+      o[0] = c1 - st_c0; o[1] = r1 - st_r0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) o[2 + k] = seg[k];
+    }
+    float chk = 0.f;                                            // keeps every accumulator (hence every MFMA) alive
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < PB; ++j) chk += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (chk == 12345.678f) ((float*)a.y)[7] = chk;
+    return;
+  }
+
+  // ---- add the two partial accumulators of a wave pair through LDS -------------------------------------------------
+  {
+    char* mb = smem + (size_t)(wq * NT) * 1024 + lane * 16;
+    if (set == 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < PB; ++j) *(f32x4v*)(mb + (i * PB + j) * 1024) = acc[i][j];
+    }
+    __syncthreads();
+    if (set == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < PB; ++j) acc[i][j] += *(const f32x4v*)(mb + (i * PB + j) * 1024);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias + activation in registers, transpose through LDS, 16-B stores along the channel axis ----------
+  if (set == 0) {
+    const float* bias = a.bias ? a.bias + (size_t)g * a.Cout + co_base : nullptr;
+    const bool act_generic = (a.act == S2P_ACT_TANH || a.act == S2P_ACT_SWISH);
+    const float ns = a.act == S2P_ACT_RELU ? 0.f : (a.act == S2P_ACT_LRELU ? a.slope : 1.f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = bias[16 * i + 4 * q + e];
+      }
+#pragma unroll
+      for (int j = 0; j < PB; ++j) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float tv = acc[i][j][e] + bv[e];
+          v[e] = act_generic ? (a.act == S2P_ACT_TANH ? tanhf(tv) : tv / (1.f + expf(-tv))) : (tv > 0.f ? tv : tv * ns);
+        }
+        const int px = (wq * PB + j) * 16 + l15;
+        bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        *(bf16x4*)(smem + px * PL_ERS + (16 * i + 4 * q) * 2) = o;
+      }
+    }
+  }
+  __syncthreads();
+  {
+    T* yg = (T*)a.y + (size_t)g * a.y_gstride;
+    const T* auxg = a.aux ? (const T*)a.aux + (size_t)g * a.y_gstride : nullptr;
+    const T* aux2g = a.aux2 ? (const T*)a.aux2 + (size_t)g * a.y_gstride : nullptr;
+    const bool epi_add = a.epi == S2P_EPI_ADD;
+    const bool g_tanh = a.gact == S2P_ACT_TANH;
+    const float gneg = a.gact == S2P_ACT_RELU ? 0.f : (a.gact == S2P_ACT_LRELU ? a.gslope : 1.f);
+    for (int idx = tid; idx < HW * 8; idx += 512) {
+      const int row = idx >> 3, ch = idx & 7;
+      Chunk<T> c;
+      c.raw = *(const u32x4*)(smem + row * PL_ERS + ch * 16);
+      const size_t go = ((size_t)img * HW + row) * a.y_pitch + co_base + ch * 8;
+      if (a.epi != S2P_EPI_STORE) {
+        Chunk<T> x, x2;
+        x.raw = *(const u32x4*)(auxg + go);
+        x2.raw = (u32x4){0u, 0u, 0u, 0u};
+        if (aux2g) x2.raw = *(const u32x4*)(aux2g + go);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float v = c.get(e), xv = x.get(e);
+          const float f = g_tanh ? 1.f - xv * xv : (xv > 0.f ? 1.f : gneg);
+          v = epi_add ? v + xv : (v + x2.get(e)) * f;
+          c.set(e, v);
+        }
+      }
+      *(u32x4*)(yg + go) = c.raw;
+    }
+  }
+}
+
+bool s2p_conv_plane_applicable(const PlaneArgs& a) {
+  if (a.H > 21 || a.W > 21 || a.H < 3 || a.W < 3) return false;      // (H+2)*22 + 2 <= 512 positions
+  const int HW = a.H * a.W;
+  if (HW > 448 || HW <= 320) return false;                              // four waves x 7 blocks of 16 px; smaller planes waste the tile
+  if (a.Cin % 64 || a.Cout % 64 || a.Cst != a.Cout) return false;
+  if (a.y_pitch % 8 || a.x_pitch % 8) return false;
+  return true;
+}
+
+int s2p_conv_plane_launch(PlaneArgs& a, int groups, hipStream_t st) {
+  a.nco = a.Cout / 64;
+  dim3 grid(a.N * a.nco, groups);
+#ifdef S2P_DIAG_BUILD
+  static const int diag = s2p_env_int("S2P_DIAG", 0);
+#define PL_DIAG_CASE(D) if (diag == D) { hipLaunchKernelGGL((conv_plane_kernel<7, 22, D>), grid, dim3(512), 0, st, a); S2P_CHECK_LAUNCH("conv_plane_kernel(diag)"); return 0; }
+  PL_DIAG_CASE(1) PL_DIAG_CASE(2) PL_DIAG_CASE(4) PL_DIAG_CASE(5) PL_DIAG_CASE(8) PL_DIAG_CASE(16) PL_DIAG_CASE(32) PL_DIAG_CASE(33) PL_DIAG_CASE(36) PL_DIAG_CASE(37) PL_DIAG_CASE(64) PL_DIAG_CASE(80)
+#undef PL_DIAG_CASE
+#endif
+  hipLaunchKernelGGL((conv_plane_kernel<7, 22, 0>), grid, dim3(512), 0, st, a);
+  S2P_CHECK_LAUNCH("conv_plane_kernel");
+  return 0;
+}

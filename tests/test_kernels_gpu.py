@@ -69,6 +69,9 @@ CONV_CASES = [
     (3, 64, 3, 1, 1, False, False, 9, 35, 3),      # ... two waves, one short band
     (3, 200, 3, 1, 1, False, False, 21, 21, 2),    # conditioning conv 3 -> many: thin-input forward kernel, 4 channel blocks (ragged)
     (3, 64, 7, 1, 3, False, True, 84, 84, 1),      # stem at the train size: thin-input forward kernel, several tiles per wave
+    (256, 128, 3, 1, 1, False, False, 19, 21, 8),  # plane-resident kernel (bf16): 8 half-slabs, XCD-aware (image, slab) order, H != W
+    (64, 64, 3, 1, 1, False, False, 20, 17, 9),    # plane-resident kernel: one co slab, 340-px plane (last blocks padded), N % 8 != 0
+    (192, 64, 3, 1, 1, False, False, 21, 21, 2),   # plane-resident kernel: odd number of 64-channel input slabs
 ]
 
 
