@@ -46,7 +46,7 @@ constexpr int PL_ERS = 144;                  // epilogue staging row: 64 co x 2 
 }
 
 // DIAG: timing ablations, instantiated only in the diagnostics build; a bit mask: 1 no in-loop DMA, 2 no MFMAs, 4 no fragment
-// reads, 8 no K loop, 16 whole-loop clock stamps, 32 per-segment stamps (waves 0 and 4); outputs are invalid for DIAG != 0.
+// reads, 8 no K loop, 16 clock stamps around the K loop, 64 coalesced (wrong) DMA sources; outputs are invalid for DIAG != 0.
 template <int PB, int WP, int DIAG>
 __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
   typedef __bf16 T;
@@ -60,6 +60,8 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
   char* const pbase = smem;
   char* const wbase = smem + 2 * PL_PBUF;
 
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};               // DIAG & 128: s_memrealtime (100 MHz) at the phase boundaries -> aux
+  if constexpr ((DIAG & 128) != 0) ph[0] = __builtin_amdgcn_s_memrealtime();
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -84,17 +86,6 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
   const unsigned p_lds = __builtin_amdgcn_readfirstlane(s2p_lds_addr(pbase));
   const unsigned w_lds = __builtin_amdgcn_readfirstlane(s2p_lds_addr(wbase));
   const unsigned OOB = 0x80000000u;
-
-  // ---- fragment read bases --------------------------------------------------------------------------------------
-  int bB[PB];
-#pragma unroll
-  for (int j = 0; j < PB; ++j) {
-    int m = (wq * PB + j) * 16 + l15;
-    if (m >= HW) m = HW - 1;                                   // padding columns of the last block: computed, never stored
-    const int y = m / a.W, x = m - y * a.W;
-    bB[j] = (q >> 1) * PL_CPS + (q & 1) * 16 + (y * WP + x) * 32;
-  }
-  const int bA = (q >> 1) * 2048 + l15 * 32 + (q & 1) * 16;
 
   // ---- DMA source offsets ---------------------------------------------------------------------------------------
   // plane: 32 pieces per half-slab (piece = 32 positions x one 16-channel pair); wave w issues pieces w, w+8, w+16, w+24
@@ -135,67 +126,59 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
     pl_dma16(wrs, w_lds + (unsigned)(stage * PL_WST) + wdst, hs < nhs ? wv : (int)OOB, tap_off + hs * 64);
   };
 
+  // ---- prologue: plane of half-slab 0 + the first three weight stages of this wave's set --------------------------------
+  issue_plane2(0, 0, 0);
+  issue_plane2(0, 0, 2);
+  issue_w(set, set ? wto[1] : wto[0], 0);                       // K steps set, set + 2, set + 4 (taps of half-slab 0)
+  issue_w(set + 2, set ? wto[3] : wto[2], 0);
+  issue_w(set + 4, set ? wto[5] : wto[4], 0);
+  // ---- fragment read bases (computed while the prologue DMA is in flight) ---------------------------------------------
+  int bB[PB];
+  {
+    const float rw = 1.0f / (float)a.W;                        // exact floor(m / W) for m < 512: (m + 0.5) / W is >= 0.5 / W away from an integer
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      int m = (wq * PB + j) * 16 + l15;
+      if (m >= HW) m = HW - 1;                                 // padding columns of the last block: computed, never stored
+      const int y = (int)(((float)m + 0.5f) * rw), x = m - y * a.W;
+      bB[j] = (q >> 1) * PL_CPS + (q & 1) * 16 + (y * WP + x) * 32;
+    }
+  }
+  const int bA = (q >> 1) * 2048 + l15 * 32 + (q & 1) * 16;
   f32x4v acc[4][PB];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < PB; ++j) acc[i][j] = (f32x4v){0.f, 0.f, 0.f, 0.f};
 
-  // ---- prologue: plane of half-slab 0 + the first weight stages ----------------------------------------------------
-  issue_plane2(0, 0, 0);
-  issue_plane2(0, 0, 2);
-  // The two wave sets run the SAME pair-step half a period apart, so that one wave of a SIMD issues MFMAs while its partner
-  // issues DMA, reads fragments and waits (MI355X_MICROARCH.md, "Two waves per SIMD", items 1 and 9): after the barrier
-  //   set 0:  DMA, fragment reads of its step, 28 MFMAs;
-  //   set 1:  28 MFMAs on the fragments it read BEFORE the barrier, then DMA and the fragment reads of its next step.
-  // Set 1 therefore reads a stage one barrier earlier and keeps its weights three pair-steps ahead (set 0: two); set 0
-  // owns the even ring stages, set 1 the odd ones.
-  auto read_frags = [&](auto uc, bf16x8 (&fa)[4], bf16x8 (&fb)[PB]) {
-    constexpr int u = decltype(uc)::value % 18;
-    constexpr int t = u % 9, hsl = u / 9, stage = u % PL_RING;
-    const char* wp = wbase + stage * PL_WST + bA;
-    const char* pp = pbase + hsl * PL_PBUF + ((t / 3) * WP + (t % 3)) * 32;
-    if constexpr ((DIAG & 4) != 0) {                      // timing ablation: no fragment reads (lane-dependent junk operands)
-      const bf16x8 junk = __builtin_bit_cast(bf16x8, (u32x4){(unsigned)bA * 2654435761u, 0x3f80bf80u, 0x3f803f80u, (unsigned)lane * 97u + 0x3f000000u});
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = junk;
-#pragma unroll
-      for (int j = 0; j < PB; ++j) fb[j] = junk;
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = *(const bf16x8*)(wp + i * 512);
-#pragma unroll
-      for (int j = 0; j < PB; ++j) fb[j] = *(const bf16x8*)(pp + bB[j]);
-    }
+  // Software pipeline, identical in both wave sets: in pair-step U a wave runs the 28 MFMAs of its K step u on fragments
+  // that are already in registers, and BETWEEN them issues the 11 fragment reads of its next step (u + 2) and its LDS-DMA
+  // pieces (weights of step u + 6 into the ring stage step u just released; its share of the next plane).  The MFMAs of
+  // the two waves of a SIMD interleave on the matrix pipe, so each wave has a ~16-cycle slot after each of its MFMAs for one
+  // of those instructions.  Set 0 runs the even K steps, set 1 the odd ones (ring stages of the same parity).
+  auto read_a = [&](auto uc, auto ic, bf16x8 (&fa)[4]) {
+    constexpr int u = decltype(uc)::value % 18, i = decltype(ic)::value;
+    if constexpr ((DIAG & 4) == 0) fa[i] = *(const bf16x8*)(wbase + (u % PL_RING) * PL_WST + i * 512 + bA);
   };
-  auto mfmas = [&](bf16x8 (&fa)[4], bf16x8 (&fb)[PB]) {
-    if constexpr ((DIAG & 2) != 0) {                                  // timing ablation: no MFMAs (the reads stay live)
+  auto read_b = [&](auto uc, auto jc, bf16x8 (&fb)[PB]) {
+    constexpr int u = decltype(uc)::value % 18, j = decltype(jc)::value;
+    constexpr int t = u % 9, hsl = u / 9;
+    if constexpr ((DIAG & 4) == 0) fb[j] = *(const bf16x8*)(pbase + hsl * PL_PBUF + ((t / 3) * WP + (t % 3)) * 32 + bB[j]);
+  };
+  auto mfma4 = [&](auto jc, bf16x8 (&fa)[4], bf16x8 (&fb)[PB]) {
+    constexpr int j = decltype(jc)::value;
+    if constexpr ((DIAG & 2) != 0) {                            // timing ablation: no MFMAs (the operands stay live)
 #pragma unroll
       for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(fa[i]));
-#pragma unroll
-      for (int j = 0; j < PB; ++j) asm volatile("" :: "v"(fb[j]));
+      asm volatile("" :: "v"(fb[j]));
     } else {
 #pragma unroll
-      for (int j = 0; j < PB; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
-  };
-  // what every wave issues in pair-step U: one weight piece (AHEAD K steps ahead of its own step u) + its share of the next planes
-  auto issue_dma = [&](auto Uc, auto uc, auto aheadc, int k2) {
-    constexpr int U = decltype(Uc)::value, u2 = decltype(uc)::value + decltype(aheadc)::value;
-    if constexpr ((DIAG & 1) == 0) {
-      issue_w(u2 % PL_RING, wto[u2 % 9], k2 + u2 / 9);
-      if constexpr (U == 0) issue_plane2(1, k2 + 1, 0);         // buffer 1 was last read in pair-step 8 of the previous iteration
-      if constexpr (U == 1) issue_plane2(1, k2 + 1, 2);
-      if constexpr (U == 5) issue_plane2(0, k2 + 2, 0);         // buffer 0 was last read in pair-step 4
-      if constexpr (U == 6) issue_plane2(0, k2 + 2, 2);
+      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
   };
   // top of pair-step U: everything this wave issued before the previous pair-step has landed (what it issued IN the previous
   // pair-step -- one weight piece, plus two plane pieces after U = 0, 1, 5, 6 -- may still be in flight), its own LDS
-  // reads have returned (another wave's DMA may overwrite what they read after the barrier), then the workgroup barrier
+  // reads have returned (another wave's DMA may overwrite what they read once the barrier is passed), then the barrier
   auto sync_top = [&](auto Uc) {
     constexpr int UP = (decltype(Uc)::value + 8) % 9;
     __builtin_amdgcn_sched_barrier(0);
@@ -205,83 +188,87 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
     __builtin_amdgcn_sched_barrier(0);
   };
   const int nloop = (DIAG & 8) ? 0 : nhs;
-  unsigned long long seg[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;  // DIAG & 32: cycles per loop segment, summed over the loop
-  auto stamp = [&](int k) {
-    if constexpr ((DIAG & 32) != 0) {
-      unsigned long long t;
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      if (k >= 0) seg[k] += t - tprev;
-      tprev = t;
-    }
-  };
-  unsigned long long st_c0 = 0, st_r0 = 0;                      // DIAG 6: shader-clock / 100 MHz stamps around the K loop -> y (output invalid)
-  if constexpr ((DIAG & 48) != 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
-  if (set == 0) {
-    issue_w(0, wto[0], 0);
-    issue_w(2, wto[2], 0);
-    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");            // (the barrier set 1 needs before its first fragment reads)
-    __builtin_amdgcn_s_barrier();
+  unsigned long long st_c0 = 0, st_r0 = 0;                      // DIAG & 16: shader-clock / 100 MHz stamps around the K loop -> y
+  auto run = [&](auto setc) {
+    constexpr int SET = decltype(setc)::value;
+    typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2; typedef std::integral_constant<int, 3> I3;
+    typedef std::integral_constant<int, 4> I4; typedef std::integral_constant<int, 5> I5;
+    typedef std::integral_constant<int, 6> I6;
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");            // plane 0 and the stage of the first step have landed ...
+    __builtin_amdgcn_s_barrier();                               // ... for every wave
     __builtin_amdgcn_sched_barrier(0);
-    stamp(-1);
+    bf16x8 fa[4], fb[PB];                                       // fragments of the step being computed
+    {
+      typedef std::integral_constant<int, SET> uc;
+      if constexpr ((DIAG & 4) != 0) {                          // timing ablation: no fragment reads (lane-dependent junk operands)
+        const bf16x8 junk = __builtin_bit_cast(bf16x8, (u32x4){(unsigned)bA * 2654435761u, 0x3f80bf80u, 0x3f803f80u, (unsigned)lane * 97u + 0x3f000000u});
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = junk;
+#pragma unroll
+        for (int j = 0; j < PB; ++j) fb[j] = junk;
+      }
+      pl_static_for<0, 4>([&](auto ic) { read_a(uc{}, ic, fa); });
+      pl_static_for<0, PB>([&](auto jc) { read_b(uc{}, jc, fb); });
+    }
+    if constexpr ((DIAG & 16) != 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+    if constexpr ((DIAG & 128) != 0) ph[1] = __builtin_amdgcn_s_memrealtime();
     for (int k2 = 0; k2 < nloop; k2 += 2) {                     // two half-slabs = 18 K steps = 9 pair-steps per iteration
       pl_static_for<0, 9>([&](auto Uc) {
         constexpr int U = decltype(Uc)::value;
-        typedef std::integral_constant<int, 2 * U> uc;
-        stamp(3);                                               // [3] top wait (vmcnt / lgkmcnt)
+        constexpr int u = 2 * U + SET;
+        typedef std::integral_constant<int, u + 2> un;           // the step whose fragments are fetched now
         sync_top(Uc);
-        stamp(4);                                               // [4] barrier
-        bf16x8 fa[4], fb[PB];
-        read_frags(uc{}, fa, fb);                               // reads first: their latency runs under the DMA issue below
+        bf16x8 na[4], nb[PB];
+        if constexpr ((DIAG & 4) != 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) na[i] = fa[i];
+#pragma unroll
+          for (int j = 0; j < PB; ++j) nb[j] = fb[j];
+        }
+        // seven groups of four MFMAs; the pinned order puts one or two LDS / DMA instructions behind each group
+        read_a(un{}, I0{}, na); read_a(un{}, I1{}, na);
+        mfma4(I0{}, fa, fb);
         __builtin_amdgcn_sched_barrier(0);
-        stamp(0);                                               // [0] fragment reads, issue to data
-        issue_dma(Uc, uc{}, std::integral_constant<int, 4>{}, k2);
+        read_a(un{}, I2{}, na); read_a(un{}, I3{}, na);
+        mfma4(I1{}, fa, fb);
         __builtin_amdgcn_sched_barrier(0);
-        stamp(1);                                               // [1] DMA issue
-        mfmas(fa, fb);
-        stamp(2);                                               // [2] MFMA issue
+        read_b(un{}, I0{}, nb); read_b(un{}, I1{}, nb);
+        if constexpr ((DIAG & 1) == 0) { constexpr int u2 = u + 6; issue_w(u2 % PL_RING, wto[u2 % 9], k2 + u2 / 9); }
+        mfma4(I2{}, fa, fb);
+        __builtin_amdgcn_sched_barrier(0);
+        read_b(un{}, I2{}, nb); read_b(un{}, I3{}, nb);
+        if constexpr ((DIAG & 1) == 0) {
+          if constexpr (U == 0) issue_plane2(1, k2 + 1, 0);     // buffer 1 was last read in pair-step 7 of the previous iteration
+          if constexpr (U == 1) issue_plane2(1, k2 + 1, 2);
+          if constexpr (U == 5) issue_plane2(0, k2 + 2, 0);     // buffer 0 was last read in pair-step 3
+          if constexpr (U == 6) issue_plane2(0, k2 + 2, 2);
+        }
+        mfma4(I3{}, fa, fb);
+        __builtin_amdgcn_sched_barrier(0);
+        read_b(un{}, I4{}, nb); read_b(un{}, I5{}, nb);
+        mfma4(I4{}, fa, fb);
+        __builtin_amdgcn_sched_barrier(0);
+        read_b(un{}, I6{}, nb);
+        mfma4(I5{}, fa, fb);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma4(I6{}, fa, fb);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = na[i];
+#pragma unroll
+        for (int j = 0; j < PB; ++j) fb[j] = nb[j];
       });
     }
-  } else {
-    issue_w(1, wto[1], 0);
-    issue_w(3, wto[3], 0);
-    issue_w(5, wto[5], 0);
-    bf16x8 fa[4], fb[PB];
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");            // plane 0 and the stage of step 1 (all waves: barrier below)
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    read_frags(std::integral_constant<int, 1>{}, fa, fb);
-    stamp(-1);
-    for (int k2 = 0; k2 < nloop; k2 += 2) {
-      pl_static_for<0, 9>([&](auto Uc) {
-        constexpr int U = decltype(Uc)::value;
-        typedef std::integral_constant<int, 2 * U + 1> uc;
-        stamp(3);
-        sync_top(Uc);
-        stamp(4);
-        mfmas(fa, fb);
-        __builtin_amdgcn_sched_barrier(0);
-        stamp(2);
-        read_frags(std::integral_constant<int, 2 * U + 3>{}, fa, fb);
-        __builtin_amdgcn_sched_barrier(0);
-        stamp(0);
-        issue_dma(Uc, uc{}, std::integral_constant<int, 6>{}, k2);
-        stamp(1);
-      });
-    }
-  }
+  };
+  if (set == 0) run(std::integral_constant<int, 0>{}); else run(std::integral_constant<int, 1>{});
   S2P_WAIT_VMCNT(0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
-  if constexpr ((DIAG & 48) != 0) {
+  if constexpr ((DIAG & 128) != 0) ph[2] = __builtin_amdgcn_s_memrealtime();
+  if constexpr ((DIAG & 16) != 0) {
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    if (lane == 0 && (wave & 3) == 0 && g == 0) {                // waves 0 (set 0) and 4 (set 1): 8 words each
-      unsigned long long* o = (unsigned long long*)a.y + ((size_t)blockIdx.x * 2 + set) * 8;
-      o[0] = c1 - st_c0; o[1] = r1 - st_r0;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) o[2 + k] = seg[k];
-    }
+    if (tid == 0 && g == 0) { unsigned long long* o = (unsigned long long*)a.y + (size_t)blockIdx.x * 2; o[0] = c1 - st_c0; o[1] = r1 - st_r0; }
     float chk = 0.f;                                            // keeps every accumulator (hence every MFMA) alive
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -291,52 +278,51 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
     return;
   }
 
-  // ---- add the two partial accumulators of a wave pair through LDS -------------------------------------------------
-  {
+  // ---- add the two partial accumulators of a wave pair through LDS: the pair exchanges halves (set 0 ends up with the sums
+  //      of co blocks 0-1, set 1 with co blocks 2-3), so all eight waves share the epilogue -----------------------------------
+  auto finish = [&](auto ibc) {
+    constexpr int IB = decltype(ibc)::value;                    // first co block this wave keeps; it hands over the other two
     char* mb = smem + (size_t)(wq * NT) * 1024 + lane * 16;
-    if (set == 1) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < PB; ++j) *(f32x4v*)(mb + (i * PB + j) * 1024) = acc[i][j];
-    }
+      for (int j = 0; j < PB; ++j) *(f32x4v*)(mb + ((2 - IB + i) * PB + j) * 1024) = acc[2 - IB + i][j];
     __syncthreads();
-    if (set == 0) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < PB; ++j) acc[i][j] += *(const f32x4v*)(mb + (i * PB + j) * 1024);
-    }
-    __syncthreads();
-  }
-
-  // ---- epilogue: bias + activation in registers, transpose through LDS, 16-B stores along the channel axis ----------
-  if (set == 0) {
+      for (int j = 0; j < PB; ++j) acc[IB + i][j] += *(const f32x4v*)(mb + ((IB + i) * PB + j) * 1024);
+    __syncthreads();                                            // the staging rows below overlap the exchange area
+    if constexpr ((DIAG & 128) != 0) ph[3] = __builtin_amdgcn_s_memrealtime();
+    // bias + activation in registers, then [pixel][co] staging rows (transpose through LDS)
     const float* bias = a.bias ? a.bias + (size_t)g * a.Cout + co_base : nullptr;
-    const bool act_generic = (a.act == S2P_ACT_TANH || a.act == S2P_ACT_SWISH);
-    const float ns = a.act == S2P_ACT_RELU ? 0.f : (a.act == S2P_ACT_LRELU ? a.slope : 1.f);
+    float bv[2][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (bias) {
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bv[e] = bias[16 * i + 4 * q + e];
-      }
+      for (int e = 0; e < 4; ++e) bv[i][e] = bias ? bias[16 * (IB + i) + 4 * q + e] : 0.f;
+    // the activation selector is resolved ONCE (a uniform branch around the whole pass), never per element
+    auto stage_out = [&](auto f) {
 #pragma unroll
-      for (int j = 0; j < PB; ++j) {
-        float v[4];
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float tv = acc[i][j][e] + bv[e];
-          v[e] = act_generic ? (a.act == S2P_ACT_TANH ? tanhf(tv) : tv / (1.f + expf(-tv))) : (tv > 0.f ? tv : tv * ns);
+        for (int j = 0; j < PB; ++j) {
+          const int px = (wq * PB + j) * 16 + l15;
+          const f32x4v v = acc[IB + i][j];
+          bf16x4 o = {(__bf16)f(v[0] + bv[i][0]), (__bf16)f(v[1] + bv[i][1]), (__bf16)f(v[2] + bv[i][2]), (__bf16)f(v[3] + bv[i][3])};
+          *(bf16x4*)(smem + px * PL_ERS + (16 * (IB + i) + 4 * q) * 2) = o;
         }
-        const int px = (wq * PB + j) * 16 + l15;
-        bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-        *(bf16x4*)(smem + px * PL_ERS + (16 * i + 4 * q) * 2) = o;
-      }
+    };
+    if (a.act == S2P_ACT_TANH) stage_out([](float v) { return tanhf(v); });
+    else if (a.act == S2P_ACT_SWISH) stage_out([](float v) { return v / (1.f + expf(-v)); });
+    else {
+      const float ns = a.act == S2P_ACT_RELU ? 0.f : (a.act == S2P_ACT_LRELU ? a.slope : 1.f);   // relu / lrelu / none
+      stage_out([ns](float v) { return v > 0.f ? v : v * ns; });
     }
-  }
+  };
+  if (set == 0) finish(std::integral_constant<int, 0>{}); else finish(std::integral_constant<int, 2>{});
   __syncthreads();
+  if constexpr ((DIAG & 128) != 0) ph[4] = __builtin_amdgcn_s_memrealtime();
   {
     T* yg = (T*)a.y + (size_t)g * a.y_gstride;
     const T* auxg = a.aux ? (const T*)a.aux + (size_t)g * a.y_gstride : nullptr;
@@ -365,6 +351,16 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
       *(u32x4*)(yg + go) = c.raw;
     }
   }
+  if constexpr ((DIAG & 128) != 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    ph[5] = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0 && g == 0 && a.aux && a.epi == S2P_EPI_STORE) {
+      unsigned long long* o = (unsigned long long*)a.aux + (size_t)blockIdx.x * 8;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) o[k] = ph[k];
+    }
+  }
 }
 
 bool s2p_conv_plane_applicable(const PlaneArgs& a) {
@@ -382,7 +378,7 @@ int s2p_conv_plane_launch(PlaneArgs& a, int groups, hipStream_t st) {
 #ifdef S2P_DIAG_BUILD
   static const int diag = s2p_env_int("S2P_DIAG", 0);
 #define PL_DIAG_CASE(D) if (diag == D) { hipLaunchKernelGGL((conv_plane_kernel<7, 22, D>), grid, dim3(512), 0, st, a); S2P_CHECK_LAUNCH("conv_plane_kernel(diag)"); return 0; }
-  PL_DIAG_CASE(1) PL_DIAG_CASE(2) PL_DIAG_CASE(4) PL_DIAG_CASE(5) PL_DIAG_CASE(8) PL_DIAG_CASE(16) PL_DIAG_CASE(32) PL_DIAG_CASE(33) PL_DIAG_CASE(36) PL_DIAG_CASE(37) PL_DIAG_CASE(64) PL_DIAG_CASE(80)
+  PL_DIAG_CASE(1) PL_DIAG_CASE(2) PL_DIAG_CASE(4) PL_DIAG_CASE(5) PL_DIAG_CASE(8) PL_DIAG_CASE(16) PL_DIAG_CASE(17) PL_DIAG_CASE(20) PL_DIAG_CASE(21) PL_DIAG_CASE(64) PL_DIAG_CASE(128)
 #undef PL_DIAG_CASE
 #endif
   hipLaunchKernelGGL((conv_plane_kernel<7, 22, 0>), grid, dim3(512), 0, st, a);

@@ -31,7 +31,7 @@ for N, cin, cout in ((64, 256, 256), (64, 128, 256), (64, 64, 256), (64, 256, 64
     out.append("N=%d cin=%d cout=%d: %.1f us %.0f TF" % (N, cin, cout, t, fl / t / 1e6))
 print("DIAG=%s  " % os.environ.get("S2P_DIAG", "0") + " | ".join(out), flush=True)
 D = int(os.environ.get("S2P_DIAG", "0"))
-if D & 48:      # in-kernel clock and per-segment cycles of the K loop (waves 0 and 4 of every workgroup)
+if D & 16:      # in-kernel clock of the K loop (wave 0 of every workgroup)
     N, cin, cout = 64, 256, 256
     geom = ops.ConvGeom(cin, cout, 3, 1, 1)
     x = torch.randn(N, 21, 21, cin, device=dev).to(dt)
@@ -39,9 +39,22 @@ if D & 48:      # in-kernel clock and per-segment cycles of the K loop (waves 0 
     for _ in range(200):                    # a few ms of back-to-back launches before the sample
         y = ops.conv_fwd(geom, x, wf, None, cin, y_pitch=cout)
     torch.cuda.synchronize()
-    st = y.view(torch.int64).flatten()[:16 * N * cout // 64].view(-1, 2, 8).cpu().double()
-    for s_ in (0, 1):
-        cyc, rt = st[:, s_, 0], st[:, s_, 1]
-        seg = st[:, s_, 2:8].median(0).values / 36
-        print("loop set %d: median %.0f cycles, %.2f us, clock %.2f GHz; per pair-step %.0f cycles = reads %.0f + dma %.0f + mfma %.0f + topwait %.0f + barrier %.0f" % (
-            s_, cyc.median(), rt.median() / 100, (cyc / rt * 0.1).median(), cyc.median() / 36, seg[0], seg[1], seg[2], seg[3], seg[4]))
+    st = y.view(torch.int64).flatten()[:2 * N * cout // 64].view(-1, 2).cpu().double()
+    cyc, rt = st[:, 0], st[:, 1]
+    print("loop: median %.0f cycles, %.2f us, clock %.2f GHz; %.0f cycles per pair-step (MFMA bound 896)" % (
+        cyc.median(), rt.median() / 100, (cyc / rt * 0.1).median(), cyc.median() / 36))
+
+if D & 128:     # phase time line of the complete kernel (realtime stamps -> aux)
+    N, cin, cout = 64, 256, 256
+    geom = ops.ConvGeom(cin, cout, 3, 1, 1)
+    x = torch.randn(N, 21, 21, cin, device=dev).to(dt)
+    wf = (torch.randn(1, cout, 9, cin, device=dev) / math.sqrt(cin * 9)).to(dt)
+    dbg = torch.zeros(N * cout // 64 * 8, dtype=torch.int64, device=dev)
+    for _ in range(200):
+        y = ops.conv_fwd(geom, x, wf, None, cin, y_pitch=cout, aux=dbg)
+    torch.cuda.synchronize()
+    st = dbg.view(-1, 8).cpu().double()[:, :6] / 100.0          # us
+    t0 = st[:, 0].min()
+    names = ["entry", "loop start", "loop end", "merged", "staged", "stored"]
+    print("phases (us after the first workgroup's entry; median / max over workgroups): " +
+          ", ".join("%s %.2f/%.2f" % (names[k], (st[:, k] - t0).median(), (st[:, k] - t0).max()) for k in range(6)))
