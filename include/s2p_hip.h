@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define S2P_VERSION 109
+#define S2P_VERSION 110
 
 enum { S2P_F32 = 0, S2P_BF16 = 1 };
 enum { S2P_ACT_NONE = 0, S2P_ACT_RELU = 1, S2P_ACT_LRELU = 2, S2P_ACT_TANH = 3, S2P_ACT_SWISH = 4 };
@@ -86,6 +86,17 @@ size_t s2p_conv2d_dgrad_workspace(const s2p_conv_desc* d);
 int s2p_conv2d_dgrad_ws(const s2p_conv_desc* d, const void* dy, const void* w_bwd,
                         const void* aux, const void* aux2, void* dx, int epi, int aux_act, float slope,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* conv -> InstanceNorm -> MAT / SPADE modulation -> activation (replaces F.conv2d followed by F.instance_norm and the
+ * `normalized * (1 + gamma) + beta` + LeakyReLU of the SPADE-lineage ResBlk: s2p_conv2d_fwd_ws + s2p_in_norm_fwd):
+ *   y      = conv(x, w) + bias  [+ aux with epi == S2P_EPI_ADD]                 (kept: the backward needs it)
+ *   y_mat  = act(IN(y) * (1 + g_img + g_st) + b_img + b_st),  stats = the statistics of y (s2p_in_stats format)
+ * For bf16 3x3 stride-1 pad-1 convs on planes of 321..448 pixels (<= 21 x 21) with Cin, Cout multiples of 64 this is ONE
+ * launch: the workgroup that owns an (image, 64-channel) plane of y normalises it in its epilogue (csrc/conv_plane.hip).
+ * Other shapes run the two calls above back to back.  groups must be 1; act: none / relu / lrelu.                     */
+int s2p_conv2d_fwd_mat(const s2p_conv_desc* d, const void* x, const void* w_fwd, const float* bias, const void* aux,
+                       void* y, int epi, const void* gb_img, int gb_pitch, const float* gb_st, int gb_st_pitch,
+                       int act, float slope, float eps, void* y_mat, int y_mat_pitch, float* stats, void* workspace,
+                       size_t workspace_bytes, void* stream);
 /* dw (fp32) [groups][Cout][KH*KW][Cin_real] for transposed==0,
  *           [groups][Cin][KH*KW][Cout_real] for transposed==1  (= channels-last physical
  * layout of the torch parameter).  dw is ACCUMULATED into (caller zeroes it);

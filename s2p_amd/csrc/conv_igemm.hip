@@ -39,6 +39,7 @@ struct GatherArgs {
   float* part; int psplit, psteps, part_m;
   void* ws; size_t ws_bytes;
   size_t* plan;                // non-null: dry run -- report the scratch bytes this launch would use, launch nothing
+  const PlaneMat* mat; int* mat_done;   // optional fused InstanceNorm + MAT epilogue (plane-resident kernel only): *mat_done = 1 when applied
   unsigned x_bytes, w_bytes;   // fast path: buffer-descriptor sizes of the gathered tensor / packed weights (per group view)
   int tap[MAX_TAPS];   // (wt << 16) | ((dx & 0xff) << 8) | (dy & 0xff)
   // merged sub-pixel phases (strided dgrad / transposed fwd on the LDS-DMA kernel): blockIdx.z selects a record that
@@ -1260,6 +1261,12 @@ static int launch_fast(GatherArgs& a, int groups, hipStream_t st) {
       p.x_bytes = a.x_bytes; p.w_bytes = a.w_bytes;
       if (s2p_conv_plane_applicable(p)) {
         if (a.plan) return 0;                              // no scratch
+        if (a.mat && groups == 1 && a.act == S2P_ACT_NONE && a.epi != S2P_EPI_MUL_ACTGRAD) {
+          p.y2 = a.mat->y2; p.y2_pitch = a.mat->y2_pitch; p.gb = a.mat->gb; p.gb_pitch = a.mat->gb_pitch;
+          p.gbst = a.mat->gbst; p.gbst_pitch = a.mat->gbst_pitch; p.stats = a.mat->stats;
+          p.n_act = a.mat->act; p.n_slope = a.mat->slope; p.eps = a.mat->eps;
+          *a.mat_done = 1;
+        }
         return s2p_conv_plane_launch(p, groups, st);
       }
     }
@@ -1336,7 +1343,7 @@ static int launch_gather(GatherArgs& a, int groups, long long x_elems, hipStream
 static int pack_tap(int dy, int dx, int wt) { return (wt << 16) | ((dx & 0xff) << 8) | (dy & 0xff); }
 
 // caller's scratch for K-split launches (ws may be null), or a dry run that only reports the bytes needed (plan)
-struct Scratch { void* ws; size_t bytes; size_t* plan; };
+struct Scratch { void* ws; size_t bytes; size_t* plan; const PlaneMat* mat; int* mat_done; };
 
 // geometry of one generic problem: gathered tensor (Hi,Wi,Ci,xpitch,xg), produced tensor (Ho,Wo,Co,Cst,ypitch,yg)
 struct Geo {
@@ -1350,7 +1357,7 @@ static int run_gather(const Geo& G, const void* x, const void* w, const float* b
                       const void* aux2, void* y,
                       int act, float slope, int epi, int gact, float gslope, hipStream_t st, const Scratch& sc) {
   GatherArgs a{};
-  a.ws = sc.ws; a.ws_bytes = sc.bytes; a.plan = sc.plan;
+  a.ws = sc.ws; a.ws_bytes = sc.bytes; a.plan = sc.plan; a.mat = sc.mat; a.mat_done = sc.mat_done;
   a.x = x; a.w = w; a.bias = bias; a.aux = aux; a.aux2 = aux2; a.y = y;
   a.Hi = G.Hi; a.Wi = G.Wi; a.Qh = G.Ho; a.Qw = G.Wo; a.M = G.N * G.Ho * G.Wo;
   a.Cin = G.Ci; a.x_pitch = G.xp; a.x_gstride = G.xg;
@@ -1503,6 +1510,21 @@ extern "C" int s2p_conv2d_fwd_ws(const s2p_conv_desc* d, const void* x, const vo
                                  const void* aux, void* y, int act, float slope, int epi, void* workspace,
                                  size_t workspace_bytes, void* stream) {
   return conv_fwd_impl(d, x, w_fwd, bias, aux, y, act, slope, epi, Scratch{workspace, workspace_bytes, nullptr}, stream);
+}
+extern "C" int s2p_conv2d_fwd_mat(const s2p_conv_desc* d, const void* x, const void* w_fwd, const float* bias, const void* aux,
+                                  void* y, int epi, const void* gb_img, int gb_pitch, const float* gb_st, int gb_st_pitch,
+                                  int act, float slope, float eps, void* y_mat, int y_mat_pitch, float* stats, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  if (!d || !y || !y_mat || !stats) S2P_FAIL(-1, "s2p_conv2d_fwd_mat: null pointer");
+  if (act != S2P_ACT_NONE && act != S2P_ACT_RELU && act != S2P_ACT_LRELU) S2P_FAIL(-1, "s2p_conv2d_fwd_mat: activation must be none / relu / lrelu");
+  if (d->groups != 1 || d->transposed) S2P_FAIL(-1, "s2p_conv2d_fwd_mat: groups == 1, not transposed");
+  PlaneMat m{y_mat, y_mat_pitch, gb_img, gb_pitch, gb_st, gb_st_pitch, stats, act, slope, eps};
+  int done = 0;
+  int rc = conv_fwd_impl(d, x, w_fwd, bias, aux, y, S2P_ACT_NONE, 0.f, epi, Scratch{workspace, workspace_bytes, nullptr, &m, &done}, stream);
+  if (rc || done) return rc;
+  // shapes the plane-resident kernel does not take: the conv above + the norm as its own launch(es)
+  return s2p_in_norm_fwd(d->dtype, y, d->N, d->Ho * d->Wo, d->Cout, d->y_pitch, gb_img, gb_pitch, gb_st, gb_st_pitch, act, slope,
+                         eps, y_mat, y_mat_pitch, stats, stream);
 }
 extern "C" size_t s2p_conv2d_fwd_workspace(const s2p_conv_desc* d, int epi) {
   size_t need = 0;

@@ -2,6 +2,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// optional fused InstanceNorm + MAT epilogue (see PlaneArgs)
+struct PlaneMat {
+  void* y2; int y2_pitch; const void* gb; int gb_pitch; const float* gbst; int gbst_pitch; float* stats; int act; float slope, eps;
+};
+
 struct PlaneArgs {
   const void* x; const void* w; const float* bias; const void* aux; const void* aux2; void* y;
   int N, H, W;                       // output grid == input grid (stride 1, pad 1)
@@ -13,6 +18,12 @@ struct PlaneArgs {
   int act, epi, gact;
   float slope, gslope;
   unsigned x_bytes, w_bytes;
+  // fused InstanceNorm + MAT modulation of the OUTPUT plane (y2 != NULL; groups must be 1): y2 = n_act(xhat * (1 + g_img + g_st)
+  // + b_img + b_st) with the statistics of y (after the residual epilogue); stats is written in norm.hip's format
+  void* y2; int y2_pitch;
+  const void* gb; int gb_pitch;      // [N, HW, gb_pitch]: gamma at channel 0, beta at channel Cout (may be NULL)
+  const float* gbst; int gbst_pitch; // fp32 [N][gbst_pitch]: gamma at [0, Cout), beta at [Cout, 2 Cout) (may be NULL)
+  float* stats; int n_act; float n_slope, eps;
   int nco;                           // set by the launcher: Cout / 64
   int diag;                          // timing ablations (diagnostics build only)
 };

@@ -47,7 +47,9 @@ constexpr int PL_ERS = 144;                  // epilogue staging row: 64 co x 2 
 
 // DIAG: timing ablations, instantiated only in the diagnostics build; a bit mask: 1 no in-loop DMA, 2 no MFMAs, 4 no fragment
 // reads, 8 no K loop, 16 clock stamps around the K loop, 64 coalesced (wrong) DMA sources; outputs are invalid for DIAG != 0.
-template <int PB, int WP, int DIAG>
+// MAT: the epilogue also InstanceNorm-alises the output plane it owns and applies the MAT / SPADE modulation + activation
+// (one more output tensor + the statistics buffer of norm.hip): conv -> IN -> modulate -> LeakyReLU in one launch.
+template <int PB, int WP, int DIAG, bool MAT = false>
 __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
   typedef __bf16 T;
   constexpr int BPIX = 4 * PB * 16;
@@ -323,32 +325,138 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
   if (set == 0) finish(std::integral_constant<int, 0>{}); else finish(std::integral_constant<int, 2>{});
   __syncthreads();
   if constexpr ((DIAG & 128) != 0) ph[4] = __builtin_amdgcn_s_memrealtime();
-  {
-    T* yg = (T*)a.y + (size_t)g * a.y_gstride;
-    const T* auxg = a.aux ? (const T*)a.aux + (size_t)g * a.y_gstride : nullptr;
-    const T* aux2g = a.aux2 ? (const T*)a.aux2 + (size_t)g * a.y_gstride : nullptr;
-    const bool epi_add = a.epi == S2P_EPI_ADD;
-    const bool g_tanh = a.gact == S2P_ACT_TANH;
-    const float gneg = a.gact == S2P_ACT_RELU ? 0.f : (a.gact == S2P_ACT_LRELU ? a.gslope : 1.f);
+  T* yg = (T*)a.y + (size_t)g * a.y_gstride;
+  const T* auxg = a.aux ? (const T*)a.aux + (size_t)g * a.y_gstride : nullptr;
+  const T* aux2g = a.aux2 ? (const T*)a.aux2 + (size_t)g * a.y_gstride : nullptr;
+  const bool epi_add = a.epi == S2P_EPI_ADD;
+  const bool g_tanh = a.gact == S2P_ACT_TANH;
+  const float gneg = a.gact == S2P_ACT_RELU ? 0.f : (a.gact == S2P_ACT_LRELU ? a.gslope : 1.f);
+  // one (pixel row, 8-channel chunk) item of the output: staged value (+ residual / producer-activation-gradient epilogue)
+  auto out_chunk = [&](int row, int ch, size_t go) {
+    Chunk<T> c;
+    c.raw = *(const u32x4*)(smem + row * PL_ERS + ch * 16);
+    if (a.epi != S2P_EPI_STORE) {
+      Chunk<T> x, x2;
+      x.raw = *(const u32x4*)(auxg + go);
+      x2.raw = (u32x4){0u, 0u, 0u, 0u};
+      if (aux2g) x2.raw = *(const u32x4*)(aux2g + go);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = c.get(e), xv = x.get(e);
+        const float f = g_tanh ? 1.f - xv * xv : (xv > 0.f ? 1.f : gneg);
+        v = epi_add ? v + xv : (v + x2.get(e)) * f;
+        c.set(e, v);
+      }
+    }
+    return c;
+  };
+  if constexpr (!MAT) {
     for (int idx = tid; idx < HW * 8; idx += 512) {
       const int row = idx >> 3, ch = idx & 7;
-      Chunk<T> c;
-      c.raw = *(const u32x4*)(smem + row * PL_ERS + ch * 16);
       const size_t go = ((size_t)img * HW + row) * a.y_pitch + co_base + ch * 8;
-      if (a.epi != S2P_EPI_STORE) {
-        Chunk<T> x, x2;
-        x.raw = *(const u32x4*)(auxg + go);
-        x2.raw = (u32x4){0u, 0u, 0u, 0u};
-        if (aux2g) x2.raw = *(const u32x4*)(aux2g + go);
+      *(u32x4*)(yg + go) = out_chunk(row, ch, go).raw;
+    }
+  } else {
+    // ---- fused InstanceNorm + MAT modulation (norm.hip: in_fused_fwd_kernel) on the plane this workgroup owns ------------
+    // Thread (row lane r = tid >> 3, chunk ch = tid & 7) holds the rows r, r + 64, ... of its 8 channels: the conv output
+    // (as stored: bf16) stays in registers, the statistics are the exact two-pass ones (mean, then centred second moment),
+    // summed in a fixed order (lanes, then waves), and the modulated tensor is written from the same registers.
+    constexpr int MAXR = BPIX / 64;
+    const int ch = tid & 7, r0 = tid >> 3;
+    const T* gbb = a.gb ? (const T*)a.gb + (size_t)img * HW * a.gb_pitch + co_base + ch * 8 : nullptr;
+    Chunk<T> xv[MAXR], gv[MAXR], bv[MAXR];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float v = c.get(e), xv = x.get(e);
-          const float f = g_tanh ? 1.f - xv * xv : (xv > 0.f ? 1.f : gneg);
-          v = epi_add ? v + xv : (v + x2.get(e)) * f;
-          c.set(e, v);
-        }
+    for (int k = 0; k < MAXR; ++k) {                             // gamma / beta first: their latency runs under the rest
+      const int row = r0 + 64 * k;
+      gv[k].raw = (u32x4){0u, 0u, 0u, 0u}; bv[k].raw = gv[k].raw;
+      if (gbb && row < HW) {
+        gv[k].raw = *(const u32x4*)(gbb + (size_t)row * a.gb_pitch);
+        bv[k].raw = *(const u32x4*)(gbb + (size_t)row * a.gb_pitch + a.Cout);
       }
-      *(u32x4*)(yg + go) = c.raw;
+    }
+#pragma unroll
+    for (int k = 0; k < MAXR; ++k) {
+      const int row = r0 + 64 * k;
+      xv[k].raw = (u32x4){0u, 0u, 0u, 0u};
+      if (row < HW) {
+        const size_t go = ((size_t)img * HW + row) * a.y_pitch + co_base + ch * 8;
+        xv[k] = out_chunk(row, ch, go);
+        *(u32x4*)(yg + go) = xv[k].raw;
+      }
+    }
+    __syncthreads();                                            // the staging rows are dead: LDS is scratch from here on
+    float* red = (float*)smem;                                  // [8 waves][64]
+    float* cst = (float*)smem + 8 * 64;                         // [4][64]: plane sum / M2, then 1 + gamma_st, beta_st
+    auto plane_sum = [&](float (&v)[8], int slot) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) v[e] += __shfl_xor(v[e], o, 64);
+      }
+      __syncthreads();
+      if (lane < 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[wave * 64 + lane * 8 + e] = v[e];
+      }
+      __syncthreads();
+      if (tid < 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += red[w * 64 + tid];
+        cst[slot * 64 + tid] = t;
+      }
+      __syncthreads();
+    };
+    const float inv = 1.f / (float)HW;
+    float sacc[8], mean[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sacc[e] = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAXR; ++k) sacc[e] += xv[k].get(e);      // rows beyond HW hold zeros
+    }
+    plane_sum(sacc, 0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      mean[e] = cst[ch * 8 + e] * inv;
+      sacc[e] = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAXR; ++k) {
+        const float d = xv[k].get(e) - mean[e];
+        sacc[e] += (r0 + 64 * k < HW) ? d * d : 0.f;
+      }
+    }
+    plane_sum(sacc, 1);
+    if (tid < 64) {
+      const int c = co_base + tid;
+      float* o = a.stats + 4 + ((size_t)img * a.Cout + c) * 2;     // norm.hip format: 4-word header, then [N][C][1 split]{mean, M2}
+      o[0] = cst[tid] * inv; o[1] = cst[64 + tid];
+      if (c == 0 && img == 0) *(i32x4*)a.stats = (i32x4){1, HW, 0, 0};
+      cst[2 * 64 + tid] = a.gbst ? 1.f + a.gbst[(size_t)img * a.gbst_pitch + c] : 1.f;
+      cst[3 * 64 + tid] = a.gbst ? a.gbst[(size_t)img * a.gbst_pitch + a.Cout + c] : 0.f;
+    }
+    __syncthreads();
+    float rstd[8], gs[8], bs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      rstd[e] = 1.f / sqrtf(cst[64 + ch * 8 + e] * inv + a.eps);
+      gs[e] = cst[2 * 64 + ch * 8 + e]; bs[e] = cst[3 * 64 + ch * 8 + e];
+    }
+    const float nns = a.n_act == S2P_ACT_RELU ? 0.f : (a.n_act == S2P_ACT_LRELU ? a.n_slope : 1.f);   // none / relu / lrelu (host)
+    T* y2 = (T*)a.y2 + (size_t)img * HW * a.y2_pitch + co_base + ch * 8;
+#pragma unroll
+    for (int k = 0; k < MAXR; ++k) {
+      const int row = r0 + 64 * k;
+      if (row >= HW) break;
+      Chunk<T> o0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float gg = gs[e] + gv[k].get(e), bb = bs[e] + bv[k].get(e);
+        const float xh = (xv[k].get(e) - mean[e]) * rstd[e];
+        const float yv = __builtin_fmaf(xh, gg, bb);              // (norm.hip: mat_value)
+        o0.set(e, yv > 0.f ? yv : yv * nns);
+      }
+      *(u32x4*)(y2 + (size_t)row * a.y2_pitch) = o0.raw;
     }
   }
   if constexpr ((DIAG & 128) != 0) {
@@ -381,6 +489,7 @@ int s2p_conv_plane_launch(PlaneArgs& a, int groups, hipStream_t st) {
   PL_DIAG_CASE(1) PL_DIAG_CASE(2) PL_DIAG_CASE(4) PL_DIAG_CASE(5) PL_DIAG_CASE(8) PL_DIAG_CASE(16) PL_DIAG_CASE(17) PL_DIAG_CASE(20) PL_DIAG_CASE(21) PL_DIAG_CASE(64) PL_DIAG_CASE(128)
 #undef PL_DIAG_CASE
 #endif
+  if (a.y2) { hipLaunchKernelGGL((conv_plane_kernel<7, 22, 0, true>), grid, dim3(512), 0, st, a); S2P_CHECK_LAUNCH("conv_plane_kernel(mat)"); return 0; }
   hipLaunchKernelGGL((conv_plane_kernel<7, 22, 0>), grid, dim3(512), 0, st, a);
   S2P_CHECK_LAUNCH("conv_plane_kernel");
   return 0;

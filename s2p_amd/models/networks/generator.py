@@ -26,6 +26,7 @@ WGRAD_CHUNK_BLOCKS = 2   # ... launched every this many finished ResBlks, under 
 STATE_SIDE_FWD = True    # state path on its side stream in the forward / in the backward (diagnostic switches)
 STATE_SIDE_BWD = True
 FUSE_SKIP_ADD = True     # ResBlk backward: the skip gradient is added inside the MAT backward launch (s2p_in_norm_bwd_res)
+FUSE_NORM_FWD = True     # ResBlk forward: InstanceNorm + MAT + LeakyReLU in the epilogue of the producing conv (s2p_conv2d_fwd_mat)
 COND_SIDE = True         # backward of the image-conditioning branch on its own stream, concurrent with the encoder backward
 
 
@@ -245,8 +246,22 @@ class S2PGenerator(BaseNetwork):
             main.wait_stream(cs)                                        # ... and the gamma/beta maps
         blocks = []
         x = a
+        nA = sA = None
         for b in range(self.n_blocks):
             o0, o1 = (2 * b) * 2 * C, (2 * b + 1) * 2 * C
+            if FUSE_NORM_FWD:
+                # every MAT norm but the first is applied in the epilogue of the conv that produces its input
+                # (s2p_conv2d_fwd_mat): conv_0 -> norm_1, and conv_1 + skip -> norm_0 of the NEXT block
+                if nA is None:
+                    nA, sA = ops.in_norm_fwd(x, C, gb_all, o0, st_all, o0, ACT_LRELU, LRELU)
+                c0, nB, sB = L[f"b{b}c0"].fwd_mat(nA, gb_all, o1, st_all, o1, ACT_LRELU, LRELU)
+                blocks.append((x, sA, nA, c0, sB, nB))
+                if b + 1 < self.n_blocks:
+                    o0n = (2 * b + 2) * 2 * C
+                    x, nA, sA = L[f"b{b}c1"].fwd_mat(nB, gb_all, o0n, st_all, o0n, ACT_LRELU, LRELU, aux=x, epi=EPI_ADD)
+                else:
+                    x = L[f"b{b}c1"].fwd(nB, aux=x, epi=EPI_ADD)
+                continue
             nA, sA = ops.in_norm_fwd(x, C, gb_all, o0, st_all, o0, ACT_LRELU, LRELU)
             c0 = L[f"b{b}c0"].fwd(nA)
             nB, sB = ops.in_norm_fwd(c0, C, gb_all, o1, st_all, o1, ACT_LRELU, LRELU)

@@ -23,6 +23,11 @@ class ConvLayer:
         return ops.conv_fwd(self.geom, x, self.pk.w_fwd, self.pk.bias, self.cin_pad(x.dtype), y_pitch=y_pitch,
                             act=act, slope=slope, aux=aux, epi=epi)
 
+    def fwd_mat(self, x, gb, gb_off, gb_st, st_off, act, slope, aux=None, epi=EPI_STORE):
+        """conv (+ residual) -> InstanceNorm -> MAT modulation -> activation; returns (conv output, modulated, stats)."""
+        return ops.conv_fwd_mat(self.geom, x, self.pk.w_fwd, self.pk.bias, self.cin_pad(x.dtype), gb, gb_off, gb_st, st_off,
+                                act=act, slope=slope, aux=aux, epi=epi)
+
     def dgrad(self, dy, x_shape, aux=None, epi=EPI_STORE, aux_act=ACT_NONE, slope=0.2, aux2=None):
         return ops.conv_dgrad(self.geom, dy, self.pk.w_bwd, tuple(x_shape), self.cin_pad(dy.dtype), aux=aux, epi=epi,
                               aux_act=aux_act, slope=slope, aux2=aux2)

@@ -112,6 +112,31 @@ def conv_fwd(geom, x, w_fwd, bias, cin_pad, y_pitch=None, act=ACT_NONE, slope=0.
     return y
 
 
+def conv_fwd_mat(geom, x, w_fwd, bias, cin_pad, gb, gb_off, gb_st, st_off, act=ACT_LRELU, slope=0.2, aux=None, epi=EPI_STORE):
+    """conv (+ bias, + residual aux) followed by InstanceNorm + MAT modulation + activation of its output, one launch where
+    the plane-resident kernel applies (s2p_conv2d_fwd_mat; conv_fwd + in_norm_fwd otherwise).
+    Returns (y, y_mat, stats): the conv output (kept for the backward), the modulated activation, the norm statistics."""
+    N, H, W, xp = x.shape
+    Ho, Wo = geom.out_hw(H, W)
+    C = geom.cout
+    y_pitch = pad_to(C, chunk_elems(x.dtype))
+    y = torch.empty((N, Ho, Wo, y_pitch), dtype=x.dtype, device=x.device)
+    y_mat = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
+    stats = torch.empty(lib().s2p_in_stats_floats(N, Ho * Wo, C), dtype=torch.float32, device=x.device)
+    d = geom.desc(x.dtype, N, H, W, cin_pad, xp, y_pitch)
+    need = lib().s2p_conv2d_fwd_workspace(ctypes.byref(d), epi)
+    ws = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None
+    gbp, gb_pitch, stp, st_pitch = _gb_args(gb, gb_off, gb_st, st_off)
+    pr = _Prof("fwd", geom, N, H, W, x.dtype)
+    if pr.on:       # the fused launch also moves the norm's bytes: gamma, beta read + the modulated tensor written
+        pr.rec["norm_bytes"] = float(N * Ho * Wo * C * x.element_size() * 3)
+    check(lib().s2p_conv2d_fwd_mat(ctypes.byref(d), ptr(x), ptr(w_fwd), ptr(bias), ptr(aux), ptr(y), epi, gbp, gb_pitch, stp,
+                                   st_pitch, act, slope, IN_EPS, ptr(y_mat), C, ptr(stats), ptr(ws), need, stream()),
+          "s2p_conv2d_fwd_mat")
+    pr.done()
+    return y, y_mat, stats
+
+
 def conv_dgrad(geom, dy, w_bwd, x_shape, cin_pad, aux=None, epi=EPI_STORE, aux_act=ACT_NONE, slope=0.2, aux2=None):
     """dx of the conv (cudnn_convolution_backward_input equivalent).  For reflect-padded convs the padded-grid
     gradient is folded back (adjoint of F.pad(mode='reflect'))."""

@@ -611,3 +611,56 @@ def test_instance_norm_backward_with_fused_residual(hip_device, dtype, HW):
     tol = 1e-6 if dtype == torch.float32 else 1.6e-2          # bf16: dx0 was rounded once before the add, dx1 only after it
     err = float((dx1.float() - ref).abs().max() / ref.abs().max())
     assert err < tol, err
+
+
+@pytest.mark.parametrize("dtype,shape", [
+    (torch.bfloat16, (8, 128, 128, 21, 21)),     # plane-resident kernel: conv + residual + IN + MAT + LeakyReLU in ONE launch
+    (torch.bfloat16, (3, 64, 192, 19, 20)),      # ... N % 8 != 0, three co slabs, 380-px plane
+    (torch.bfloat16, (2, 64, 64, 9, 7)),         # small plane: conv launch + norm launch behind the same entry point
+    (torch.float32, (2, 16, 32, 21, 21)),        # fp32 parity path: two launches
+])
+@pytest.mark.parametrize("residual", [False, True])
+def test_conv_fwd_mat_fused(hip_device, dtype, shape, residual):
+    """s2p_conv2d_fwd_mat == F.conv2d (+ skip) -> F.instance_norm -> x_hat * (1 + gamma) + beta -> LeakyReLU, and the
+    statistics buffer it leaves is the one s2p_in_norm_bwd consumes."""
+    dev = hip_device
+    N, cin, cout, H, W = shape
+    if residual and cin != cout:
+        pytest.skip("residual needs cin == cout")
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g)
+    gb = torch.randn(N, 2 * cout + 16, H, W, generator=g) * 0.5      # gamma | beta at a channel offset inside a wider tensor
+    st = torch.randn(N, 2 * cout + 8, generator=g) * 0.5
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float(); w = w.bfloat16().float(); gb = gb.bfloat16().float()
+    geom = ops.ConvGeom(cin, cout, 3, 1, 1)
+    xd = nhwc(x, cin, dtype, dev)
+    wf = pack_fwd(w, cin, dtype, dev)
+    gbd = nhwc(gb, 2 * cout + 16, dtype, dev)
+    std = st.to(dev)
+    y, ym, stats = ops.conv_fwd_mat(geom, xd, wf, b.to(dev), cin, gbd, 16, std, 8, act=ACT_LRELU, slope=0.2,
+                                    aux=xd if residual else None, epi=EPI_ADD if residual else EPI_STORE)
+    torch.cuda.synchronize()
+    y_ref = F.conv2d(x.double(), w.double(), b.double(), padding=1) + (x.double() if residual else 0)
+    assert rel_err(nchw(y, cout), y_ref) < TOL[dtype]
+    # the norm is applied to the tensor the kernel STORED (bf16-rounded on the bf16 path)
+    ys = nchw(y, cout).double()
+    mean = ys.mean((2, 3), keepdim=True); var = ys.var((2, 3), unbiased=False, keepdim=True)
+    xh = (ys - mean) / torch.sqrt(var + 1e-5)
+    gam = gb[:, 16:16 + cout].double() + st[:, 8:8 + cout].double()[:, :, None, None]
+    bet = gb[:, 16 + cout:16 + 2 * cout].double() + st[:, 8 + cout:8 + 2 * cout].double()[:, :, None, None]
+    ym_ref = F.leaky_relu(xh * (1 + gam) + bet, 0.2)
+    assert rel_err(nchw(ym, cout), ym_ref) < (1e-5 if dtype == torch.float32 else 6e-3)
+    # same result as the two separate calls, and the statistics buffer feeds the norm backward
+    ym2, stats2 = ops.in_norm_fwd(y, cout, gbd, 16, std, 8, ACT_LRELU, 0.2)
+    assert rel_err(ym.float().cpu(), ym2.float().cpu().double()) < (1e-5 if dtype == torch.float32 else 6e-3)
+    da = torch.randn(N, cout, H, W, generator=g)
+    if dtype == torch.bfloat16:
+        da = da.bfloat16().float()
+    dad = nhwc(da, cout, dtype, dev)
+    dx1 = ops.in_bwd(dad, y, cout, stats, gbd, 16, std, 8, ACT_LRELU, 0.2, torch.empty_like(gbd), 16, torch.empty_like(std), 8)
+    dx2 = ops.in_bwd(dad, y, cout, stats2, gbd, 16, std, 8, ACT_LRELU, 0.2, torch.empty_like(gbd), 16, torch.empty_like(std), 8)
+    torch.cuda.synchronize()
+    assert rel_err(dx1.float().cpu(), dx2.float().cpu().double()) < (1e-5 if dtype == torch.float32 else 6e-3)
