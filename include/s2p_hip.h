@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define S2P_VERSION 110
+#define S2P_VERSION 111
 
 enum { S2P_F32 = 0, S2P_BF16 = 1 };
 enum { S2P_ACT_NONE = 0, S2P_ACT_RELU = 1, S2P_ACT_LRELU = 2, S2P_ACT_TANH = 3, S2P_ACT_SWISH = 4 };
@@ -97,6 +97,18 @@ int s2p_conv2d_fwd_mat(const s2p_conv_desc* d, const void* x, const void* w_fwd,
                        void* y, int epi, const void* gb_img, int gb_pitch, const float* gb_st, int gb_st_pitch,
                        int act, float slope, float eps, void* y_mat, int y_mat_pitch, float* stats, void* workspace,
                        size_t workspace_bytes, void* stream);
+/* The backward counterpart: dgrad of a conv whose INPUT was the output of a MAT norm, followed by that norm's backward
+ * (s2p_conv2d_dgrad_ws + s2p_in_norm_bwd_res).  d describes the conv (forward orientation); dy = dL/d(conv output);
+ * xn / stats / gb_img / gb_st / act: the norm's input, statistics and modulation as in s2p_in_norm_bwd; outputs
+ * dxn = dL/d(xn) (+ res), dgb_img, dgb_st as there.  Under the conditions of s2p_conv2d_fwd_mat (on the dgrad: Cout is the
+ * contraction, Cin the produced channels) this is ONE launch and dL/d(norm output) never reaches HBM; otherwise it is
+ * written to d_mid ([N,H,W,x_pitch], always required) and the norm backward runs as its own launch(es) (needs `sums`:
+ * s2p_in_bwd_sums_floats(N, H*W, Cin) floats).                                                                        */
+int s2p_conv2d_dgrad_mat(const s2p_conv_desc* d, const void* dy, const void* w_bwd, void* d_mid, const void* xn,
+                         int xn_pitch, const float* stats, const void* gb_img, int gb_pitch, const float* gb_st,
+                         int gb_st_pitch, int act, float slope, float eps, float* sums, void* dxn, int dxn_pitch,
+                         void* dgb_img, int dgb_pitch, float* dgb_st, int dgb_st_pitch, const void* res, int res_pitch,
+                         void* workspace, size_t workspace_bytes, void* stream);
 /* dw (fp32) [groups][Cout][KH*KW][Cin_real] for transposed==0,
  *           [groups][Cin][KH*KW][Cout_real] for transposed==1  (= channels-last physical
  * layout of the torch parameter).  dw is ACCUMULATED into (caller zeroes it);

@@ -1261,7 +1261,9 @@ static int launch_fast(GatherArgs& a, int groups, hipStream_t st) {
       p.x_bytes = a.x_bytes; p.w_bytes = a.w_bytes;
       if (s2p_conv_plane_applicable(p)) {
         if (a.plan) return 0;                              // no scratch
-        if (a.mat && groups == 1 && a.act == S2P_ACT_NONE && a.epi != S2P_EPI_MUL_ACTGRAD) {
+        if (a.mat && groups == 1 && a.act == S2P_ACT_NONE && a.epi != S2P_EPI_MUL_ACTGRAD && (!a.mat->xn || a.epi == S2P_EPI_STORE)) {
+          p.xn = a.mat->xn; p.xn_pitch = a.mat->xn_pitch; p.dgb = a.mat->dgb; p.dgb_pitch = a.mat->dgb_pitch;
+          p.dgbst = a.mat->dgbst; p.dgbst_pitch = a.mat->dgbst_pitch; p.res = a.mat->res; p.res_pitch = a.mat->res_pitch;
           p.y2 = a.mat->y2; p.y2_pitch = a.mat->y2_pitch; p.gb = a.mat->gb; p.gb_pitch = a.mat->gb_pitch;
           p.gbst = a.mat->gbst; p.gbst_pitch = a.mat->gbst_pitch; p.stats = a.mat->stats;
           p.n_act = a.mat->act; p.n_slope = a.mat->slope; p.eps = a.mat->eps;
@@ -1434,7 +1436,7 @@ static int run_scatter(const Geo& G, const void* x, const void* w, const float* 
   for (int py = 0; py < s; ++py)
     for (int px = 0; px < s; ++px) {
       GatherArgs a{};
-      a.ws = sc.ws; a.ws_bytes = sc.bytes; a.plan = sc.plan;
+      a.ws = sc.ws; a.ws_bytes = sc.bytes; a.plan = sc.plan; a.mat = sc.mat; a.mat_done = sc.mat_done;
       a.x = x; a.w = w; a.bias = bias; a.aux = aux; a.aux2 = aux2; a.y = y;
       a.Hi = G.Hi; a.Wi = G.Wi;
       a.Qh = (G.Ho - py + s - 1) / s; a.Qw = (G.Wo - px + s - 1) / s;
@@ -1518,7 +1520,7 @@ extern "C" int s2p_conv2d_fwd_mat(const s2p_conv_desc* d, const void* x, const v
   if (!d || !y || !y_mat || !stats) S2P_FAIL(-1, "s2p_conv2d_fwd_mat: null pointer");
   if (act != S2P_ACT_NONE && act != S2P_ACT_RELU && act != S2P_ACT_LRELU) S2P_FAIL(-1, "s2p_conv2d_fwd_mat: activation must be none / relu / lrelu");
   if (d->groups != 1 || d->transposed) S2P_FAIL(-1, "s2p_conv2d_fwd_mat: groups == 1, not transposed");
-  PlaneMat m{y_mat, y_mat_pitch, gb_img, gb_pitch, gb_st, gb_st_pitch, stats, act, slope, eps};
+  PlaneMat m{y_mat, y_mat_pitch, gb_img, gb_pitch, gb_st, gb_st_pitch, stats, act, slope, eps, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0};
   int done = 0;
   int rc = conv_fwd_impl(d, x, w_fwd, bias, aux, y, S2P_ACT_NONE, 0.f, epi, Scratch{workspace, workspace_bytes, nullptr, &m, &done}, stream);
   if (rc || done) return rc;
@@ -1569,6 +1571,25 @@ extern "C" int s2p_conv2d_dgrad_ws(const s2p_conv_desc* d, const void* dy, const
                                    const void* aux2, void* dx, int epi, int aux_act, float slope, void* workspace,
                                    size_t workspace_bytes, void* stream) {
   return conv_dgrad_impl(d, dy, w_bwd, aux, aux2, dx, epi, aux_act, slope, Scratch{workspace, workspace_bytes, nullptr}, stream);
+}
+extern "C" int s2p_conv2d_dgrad_mat(const s2p_conv_desc* d, const void* dy, const void* w_bwd, void* d_mid, const void* xn,
+                                    int xn_pitch, const float* stats, const void* gb_img, int gb_pitch, const float* gb_st,
+                                    int gb_st_pitch, int act, float slope, float eps, float* sums, void* dxn, int dxn_pitch,
+                                    void* dgb_img, int dgb_pitch, float* dgb_st, int dgb_st_pitch, const void* res, int res_pitch,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  if (!d || !d_mid || !xn || !stats || !dxn) S2P_FAIL(-1, "s2p_conv2d_dgrad_mat: null pointer");
+  if (act != S2P_ACT_NONE && act != S2P_ACT_RELU && act != S2P_ACT_LRELU) S2P_FAIL(-1, "s2p_conv2d_dgrad_mat: activation must be none / relu / lrelu");
+  if (d->groups != 1 || d->transposed || d->reflect) S2P_FAIL(-1, "s2p_conv2d_dgrad_mat: groups == 1, not transposed, zero padding");
+  PlaneMat m{dxn, dxn_pitch, gb_img, gb_pitch, gb_st, gb_st_pitch, const_cast<float*>(stats), act, slope, eps,
+             xn, xn_pitch, dgb_img, dgb_pitch, dgb_st, dgb_st_pitch, res, res_pitch};
+  int done = 0;
+  int rc = conv_dgrad_impl(d, dy, w_bwd, nullptr, nullptr, d_mid, S2P_EPI_STORE, S2P_ACT_NONE, 0.f,
+                           Scratch{workspace, workspace_bytes, nullptr, &m, &done}, stream);
+  if (rc || done) return rc;
+  // shapes the plane-resident kernel does not take: the dgrad above wrote d_mid; the norm backward as its own launch(es)
+  return s2p_in_norm_bwd_res(d->dtype, d_mid, d->x_pitch, xn, d->N, d->H * d->W, d->Cin, xn_pitch, stats, gb_img, gb_pitch, gb_st,
+                             gb_st_pitch, act, slope, eps, sums, dxn, dxn_pitch, dgb_img, dgb_pitch, dgb_st, dgb_st_pitch, res,
+                             res_pitch, stream);
 }
 extern "C" size_t s2p_conv2d_dgrad_workspace(const s2p_conv_desc* d) {
   size_t need = 0;

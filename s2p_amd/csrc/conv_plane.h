@@ -5,6 +5,7 @@
 // optional fused InstanceNorm + MAT epilogue (see PlaneArgs)
 struct PlaneMat {
   void* y2; int y2_pitch; const void* gb; int gb_pitch; const float* gbst; int gbst_pitch; float* stats; int act; float slope, eps;
+  const void* xn; int xn_pitch; void* dgb; int dgb_pitch; float* dgbst; int dgbst_pitch; const void* res; int res_pitch;   // backward form
 };
 
 struct PlaneArgs {
@@ -24,6 +25,10 @@ struct PlaneArgs {
   const void* gb; int gb_pitch;      // [N, HW, gb_pitch]: gamma at channel 0, beta at channel Cout (may be NULL)
   const float* gbst; int gbst_pitch; // fp32 [N][gbst_pitch]: gamma at [0, Cout), beta at [Cout, 2 Cout) (may be NULL)
   float* stats; int n_act; float n_slope, eps;
+  // fused BACKWARD of that norm (xn != NULL; this launch is the dgrad of the conv the norm fed): the conv result is
+  // dL/d(norm output) and is not stored (y unused); y2 = dL/d(xn) + res, dgb / dgbst = d(gamma | beta) of the image map /
+  // the state affine; stats is read (the forward's)
+  const void* xn; int xn_pitch; void* dgb; int dgb_pitch; float* dgbst; int dgbst_pitch; const void* res; int res_pitch;
   int nco;                           // set by the launcher: Cout / 64
   int diag;                          // timing ablations (diagnostics build only)
 };

@@ -49,7 +49,7 @@ constexpr int PL_ERS = 144;                  // epilogue staging row: 64 co x 2 
 // reads, 8 no K loop, 16 clock stamps around the K loop, 64 coalesced (wrong) DMA sources; outputs are invalid for DIAG != 0.
 // MAT: the epilogue also InstanceNorm-alises the output plane it owns and applies the MAT / SPADE modulation + activation
 // (one more output tensor + the statistics buffer of norm.hip): conv -> IN -> modulate -> LeakyReLU in one launch.
-template <int PB, int WP, int DIAG, bool MAT = false>
+template <int PB, int WP, int DIAG, int MAT = 0>   // MAT: 0 plain conv, 1 + forward norm, 2 + backward of the norm that FED this dgrad's forward conv
 __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
   typedef __bf16 T;
   constexpr int BPIX = 4 * PB * 16;
@@ -350,13 +350,13 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
     }
     return c;
   };
-  if constexpr (!MAT) {
+  if constexpr (MAT == 0) {
     for (int idx = tid; idx < HW * 8; idx += 512) {
       const int row = idx >> 3, ch = idx & 7;
       const size_t go = ((size_t)img * HW + row) * a.y_pitch + co_base + ch * 8;
       *(u32x4*)(yg + go) = out_chunk(row, ch, go).raw;
     }
-  } else {
+  } else if constexpr (MAT == 1) {
     // ---- fused InstanceNorm + MAT modulation (norm.hip: in_fused_fwd_kernel) on the plane this workgroup owns ------------
     // Thread (row lane r = tid >> 3, chunk ch = tid & 7) holds the rows r, r + 64, ... of its 8 channels: the conv output
     // (as stored: bf16) stays in registers, the statistics are the exact two-pass ones (mean, then centred second moment),
@@ -459,6 +459,118 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
       *(u32x4*)(y2 + (size_t)row * a.y2_pitch) = o0.raw;
     }
   }
+  if constexpr (MAT == 2) {
+    // ---- fused backward of InstanceNorm + MAT modulation + activation (norm.hip: in_fused_bwd_kernel) ---------------------
+    // This launch is the dgrad of the conv that CONSUMED the norm's output, so the staged plane is dL/d(norm output) for the
+    // (image, 64-channel slab) this workgroup owns; it never goes to HBM.  Thread (row lane r0 = tid >> 3, chunk ch = tid & 7)
+    // loads the norm INPUT xn, gamma and beta of its rows, forms the four plane sums (lanes, then waves: fixed order) and
+    // writes dL/d(xn) (+ the skip gradient `res`), d(gamma_img | beta_img) and the state-affine gradient.
+    constexpr int MAXR = BPIX / 64;
+    const int ch = tid & 7, r0 = tid >> 3, lc = co_base + ch * 8;
+    const T* xb = (const T*)a.xn + (size_t)img * HW * a.xn_pitch + lc;
+    const T* gbb = a.gb ? (const T*)a.gb + (size_t)img * HW * a.gb_pitch + lc : nullptr;
+    Chunk<T> xv[MAXR], gv[MAXR], bv[MAXR], dv[MAXR];
+#pragma unroll
+    for (int k = 0; k < MAXR; ++k) {
+      const int row = r0 + 64 * k;
+      xv[k].raw = (u32x4){0u, 0u, 0u, 0u}; gv[k].raw = xv[k].raw; bv[k].raw = xv[k].raw; dv[k].raw = xv[k].raw;
+      if (row < HW) {
+        xv[k].raw = *(const u32x4*)(xb + (size_t)row * a.xn_pitch);
+        if (gbb) { gv[k].raw = *(const u32x4*)(gbb + (size_t)row * a.gb_pitch); bv[k].raw = *(const u32x4*)(gbb + (size_t)row * a.gb_pitch + a.Cout); }
+        dv[k].raw = *(const u32x4*)(smem + row * PL_ERS + ch * 16);     // rows beyond HW stay zero: they add nothing to the sums
+      }
+    }
+    __syncthreads();                                            // the staging rows are dead: LDS is scratch from here on
+    float* red = (float*)smem;                                  // [4 sums][8 waves][64]
+    float* cst = (float*)smem + 4 * 8 * 64;                     // [6][64]: mean, rstd, 1 + gamma_st, beta_st, s1 / HW, s2 / HW
+    if (tid < 64) {
+      const int c = co_base + tid;
+      // merge the per-split partial moments (norm.hip: mean_rstd; S = 1 when a fused forward kernel wrote them)
+      const int S = ((const int*)a.stats)[0], rows = ((const int*)a.stats)[1];
+      const float* pm = a.stats + 4 + ((size_t)img * a.Cout + c) * S * 2;
+      const float inv = 1.f / (float)HW;
+      const float m0 = pm[0];
+      float m = 0.f;
+      for (int b = 1; b < S; ++b) { int nb = HW - b * rows; if (nb > rows) nb = rows; m += (float)nb * (pm[2 * b] - m0); }
+      m = m0 + m * inv;
+      float M2 = 0.f;
+      for (int b = 0; b < S; ++b) { int nb = HW - b * rows; if (nb > rows) nb = rows; const float dd = pm[2 * b] - m; M2 += pm[2 * b + 1] + (float)nb * dd * dd; }
+      cst[tid] = m; cst[64 + tid] = 1.f / sqrtf(M2 * inv + a.eps);
+      cst[2 * 64 + tid] = a.gbst ? 1.f + a.gbst[(size_t)img * a.gbst_pitch + c] : 1.f;
+      cst[3 * 64 + tid] = a.gbst ? a.gbst[(size_t)img * a.gbst_pitch + a.Cout + c] : 0.f;
+    }
+    __syncthreads();
+    const float gneg = a.n_act == S2P_ACT_RELU ? 0.f : (a.n_act == S2P_ACT_LRELU ? a.n_slope : 1.f);
+    unsigned long long posmask = 0ull;                          // activation branch per (row k, element e): pass 2 reuses pass 1's
+    // ---- pass 1: the four plane sums
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int cl = ch * 8 + e;
+      const float m = cst[cl], r = cst[64 + cl], g1 = cst[128 + cl], b1 = cst[192 + cl];
+      float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAXR; ++k) {
+        const float gg = g1 + gv[k].get(e), bb = b1 + bv[k].get(e);
+        const float xh = (xv[k].get(e) - m) * r;
+        const float yv = __builtin_fmaf(xh, gg, bb);            // (norm.hip: mat_value -- the forward's rounding)
+        const bool pos = yv > 0.f;
+        posmask |= pos ? (1ull << (k * 8 + e)) : 0ull;
+        const float dy = dv[k].get(e) * (pos ? 1.f : gneg);
+        const float dxh = dy * gg;
+        q0 += dxh; q1 += dxh * xh; q2 += dy * xh; q3 += dy;
+      }
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) {
+        q0 += __shfl_xor(q0, o, 64); q1 += __shfl_xor(q1, o, 64); q2 += __shfl_xor(q2, o, 64); q3 += __shfl_xor(q3, o, 64);
+      }
+      if (lane < 8) { red[(0 * 8 + wave) * 64 + cl] = q0; red[(1 * 8 + wave) * 64 + cl] = q1; red[(2 * 8 + wave) * 64 + cl] = q2; red[(3 * 8 + wave) * 64 + cl] = q3; }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { t0 += red[(0 * 8 + w) * 64 + tid]; t1 += red[(1 * 8 + w) * 64 + tid]; t2 += red[(2 * 8 + w) * 64 + tid]; t3 += red[(3 * 8 + w) * 64 + tid]; }
+      const float inv = 1.f / (float)HW;
+      cst[4 * 64 + tid] = t0 * inv; cst[5 * 64 + tid] = t1 * inv;
+      const int c = co_base + tid;
+      if (a.dgbst) {
+        a.dgbst[(size_t)img * a.dgbst_pitch + c] = t2;
+        a.dgbst[(size_t)img * a.dgbst_pitch + a.Cout + c] = t3;
+      }
+    }
+    __syncthreads();
+    // ---- pass 2: outputs
+    T* dxo = (T*)a.y2 + (size_t)img * HW * a.y2_pitch + lc;
+    T* dgo = a.dgb ? (T*)a.dgb + (size_t)img * HW * a.dgb_pitch + lc : nullptr;
+    const T* rsb = a.res ? (const T*)a.res + (size_t)img * HW * a.res_pitch + lc : nullptr;
+#pragma unroll
+    for (int k = 0; k < MAXR; ++k) {
+      const int row = r0 + 64 * k;
+      if (row >= HW) break;
+      Chunk<T> o0, o1, o2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int cl = ch * 8 + e;
+        const float m = cst[cl], r = cst[64 + cl], gg = cst[128 + cl] + gv[k].get(e), s1 = cst[256 + cl], s2 = cst[320 + cl];
+        const float xh = (xv[k].get(e) - m) * r;
+        const float dy = dv[k].get(e) * (((posmask >> (k * 8 + e)) & 1ull) ? 1.f : gneg);
+        const float dxh = dy * gg;
+        o0.set(e, r * (dxh - s1 - xh * s2));
+        o1.set(e, dy * xh);
+        o2.set(e, dy);
+      }
+      if (rsb) {                                                // skip-connection gradient folded into the store (fp32 add, one rounding)
+        Chunk<T> rv; rv.raw = *(const u32x4*)(rsb + (size_t)row * a.res_pitch);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o0.set(e, o0.get(e) + rv.get(e));
+      }
+      *(u32x4*)(dxo + (size_t)row * a.y2_pitch) = o0.raw;
+      if (dgo) {
+        *(u32x4*)(dgo + (size_t)row * a.dgb_pitch) = o1.raw;
+        *(u32x4*)(dgo + (size_t)row * a.dgb_pitch + a.Cout) = o2.raw;
+      }
+    }
+  }
   if constexpr ((DIAG & 128) != 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -489,7 +601,8 @@ int s2p_conv_plane_launch(PlaneArgs& a, int groups, hipStream_t st) {
   PL_DIAG_CASE(1) PL_DIAG_CASE(2) PL_DIAG_CASE(4) PL_DIAG_CASE(5) PL_DIAG_CASE(8) PL_DIAG_CASE(16) PL_DIAG_CASE(17) PL_DIAG_CASE(20) PL_DIAG_CASE(21) PL_DIAG_CASE(64) PL_DIAG_CASE(128)
 #undef PL_DIAG_CASE
 #endif
-  if (a.y2) { hipLaunchKernelGGL((conv_plane_kernel<7, 22, 0, true>), grid, dim3(512), 0, st, a); S2P_CHECK_LAUNCH("conv_plane_kernel(mat)"); return 0; }
+  if (a.y2 && a.xn) { hipLaunchKernelGGL((conv_plane_kernel<7, 22, 0, 2>), grid, dim3(512), 0, st, a); S2P_CHECK_LAUNCH("conv_plane_kernel(mat bwd)"); return 0; }
+  if (a.y2) { hipLaunchKernelGGL((conv_plane_kernel<7, 22, 0, 1>), grid, dim3(512), 0, st, a); S2P_CHECK_LAUNCH("conv_plane_kernel(mat)"); return 0; }
   hipLaunchKernelGGL((conv_plane_kernel<7, 22, 0>), grid, dim3(512), 0, st, a);
   S2P_CHECK_LAUNCH("conv_plane_kernel");
   return 0;

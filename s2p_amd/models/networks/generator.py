@@ -27,6 +27,7 @@ STATE_SIDE_FWD = True    # state path on its side stream in the forward / in the
 STATE_SIDE_BWD = True
 FUSE_SKIP_ADD = True     # ResBlk backward: the skip gradient is added inside the MAT backward launch (s2p_in_norm_bwd_res)
 FUSE_NORM_FWD = True     # ResBlk forward: InstanceNorm + MAT + LeakyReLU in the epilogue of the producing conv (s2p_conv2d_fwd_mat)
+FUSE_NORM_BWD = True     # ResBlk backward: each MAT norm's backward in the epilogue of the following dgrad (s2p_conv2d_dgrad_mat)
 COND_SIDE = True         # backward of the image-conditioning branch on its own stream, concurrent with the encoder backward
 
 
@@ -351,6 +352,17 @@ class S2PGenerator(BaseNetwork):
         for k, b in enumerate(reversed(range(self.n_blocks))):
             x, sA, nA, c0, sB, nB = ctx["blocks"][b]
             o0, o1 = (2 * b) * 2 * C, (2 * b + 1) * 2 * C
+            if FUSE_NORM_BWD:
+                # each MAT norm's backward runs in the epilogue of the dgrad of the conv it fed (s2p_conv2d_dgrad_mat):
+                # dL/d(norm output) never goes to HBM; the skip gradient is added in the second launch
+                wjobs.append((L[f"b{b}c1"], nB, dx))
+                d_c0 = L[f"b{b}c1"].dgrad_mat(dx, c0, sB, gb_all, o1, st_all, o1, ACT_LRELU, LRELU, dgb_all, o1, dst_all, o1)
+                wjobs.append((L[f"b{b}c0"], nA, d_c0))
+                dx = L[f"b{b}c0"].dgrad_mat(d_c0, x, sA, gb_all, o0, st_all, o0, ACT_LRELU, LRELU, dgb_all, o0, dst_all, o0, res=dx)
+                if ws is not None and WGRAD_CHUNK_BLOCKS > 0 and (k + 1) % WGRAD_CHUNK_BLOCKS == 0 and k + 1 < self.n_blocks:
+                    side_wgrads(wjobs)
+                    wjobs = []
+                continue
             wjobs.append((L[f"b{b}c1"], nB, dx))
             d_nB = L[f"b{b}c1"].dgrad(dx, nB.shape)
             d_c0 = ops.in_bwd(d_nB, c0, C, sB, gb_all, o1, st_all, o1, ACT_LRELU, LRELU, dgb_all, o1, dst_all, o1)

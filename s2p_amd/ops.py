@@ -171,6 +171,34 @@ def conv_dgrad(geom, dy, w_bwd, x_shape, cin_pad, aux=None, epi=EPI_STORE, aux_a
     return dx
 
 
+def conv_dgrad_mat(geom, dy, w_bwd, xn, cin_pad, stats, gb, gb_off, gb_st, st_off, act, slope, dgb, dgb_off, dgb_st, dst_off,
+                   res=None):
+    """dgrad of a conv whose input was a MAT norm's output, fused with that norm's backward (s2p_conv2d_dgrad_mat):
+    returns dL/d(xn) (+ res); writes d(gamma|beta) as in_bwd does.  xn: the norm's input [N,H,W,C]."""
+    N, H, W, xp = xn.shape
+    C = geom.cin
+    d = geom.desc(dy.dtype, N, H, W, cin_pad, C, dy.shape[3])
+    dxn = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
+    d_mid = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)      # only touched on the two-launch path
+    sums = torch.empty(lib().s2p_in_bwd_sums_floats(N, H * W, C), dtype=torch.float32, device=dy.device)
+    need = lib().s2p_conv2d_dgrad_workspace(ctypes.byref(d))
+    ws = torch.empty(need, dtype=torch.uint8, device=dy.device) if need else None
+    gbp, gb_pitch, stp, st_pitch = _gb_args(gb, gb_off, gb_st, st_off)
+    dgbp = dgb.data_ptr() + dgb_off * dgb.element_size() if dgb is not None else None
+    dstp = dgb_st.data_ptr() + dst_off * 4 if dgb_st is not None else None
+    _ = ptr(dgb), ptr(dgb_st)
+    if res is not None:
+        assert res.shape == dxn.shape and res.dtype == dxn.dtype and res.is_contiguous()
+    pr = _Prof("dgrad", geom, N, H, W, dy.dtype)
+    check(lib().s2p_conv2d_dgrad_mat(ctypes.byref(d), ptr(dy), ptr(w_bwd), ptr(d_mid), ptr(xn), xp, ptr(stats), gbp, gb_pitch,
+                                     stp, st_pitch, act, slope, IN_EPS, ptr(sums), ptr(dxn), C, dgbp,
+                                     dgb.shape[3] if dgb is not None else 0, dstp,
+                                     dgb_st.shape[1] if dgb_st is not None else 0, ptr(res), C if res is not None else 0,
+                                     ptr(ws), need, stream()), "s2p_conv2d_dgrad_mat")
+    pr.done()
+    return dxn
+
+
 def conv_wgrad(geom, x, dy, dw, cin_pad, cin_real, cout_real, dw_gstride=0, splitk=0, db=None):
     """dw += wgrad (cudnn_convolution_backward_weight equivalent); dw is an fp32 view in channels-last layout.
     The K-split partial sums go through a scratch buffer and are added in a fixed order (s2p_conv2d_wgrad_ws): no atomics."""

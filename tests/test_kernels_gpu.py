@@ -664,3 +664,56 @@ def test_conv_fwd_mat_fused(hip_device, dtype, shape, residual):
     dx2 = ops.in_bwd(dad, y, cout, stats2, gbd, 16, std, 8, ACT_LRELU, 0.2, torch.empty_like(gbd), 16, torch.empty_like(std), 8)
     torch.cuda.synchronize()
     assert rel_err(dx1.float().cpu(), dx2.float().cpu().double()) < (1e-5 if dtype == torch.float32 else 6e-3)
+
+
+@pytest.mark.parametrize("dtype,shape", [
+    (torch.bfloat16, (8, 128, 128, 21, 21)),     # plane-resident kernel: dgrad + MAT-norm backward in ONE launch
+    (torch.bfloat16, (3, 192, 64, 19, 20)),      # ... N % 8 != 0, 380-px plane, three input-channel slabs produced
+    (torch.bfloat16, (2, 64, 64, 9, 7)),         # small plane: two launches behind the same entry point
+    (torch.float32, (2, 16, 32, 21, 21)),        # fp32 parity path: two launches
+])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_conv_dgrad_mat_fused(hip_device, dtype, shape, with_res):
+    """s2p_conv2d_dgrad_mat == conv dgrad -> backward of (InstanceNorm -> MAT modulation -> LeakyReLU) [+ skip gradient],
+    against the float64 autograd of the same chain and against the two separate HIP calls."""
+    dev = hip_device
+    N, C, cout, H, W = shape                      # the norm has C channels and feeds a conv C -> cout
+    g = torch.Generator().manual_seed(13)
+    xn = torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3
+    w = torch.randn(cout, C, 3, 3, generator=g) / math.sqrt(C * 9)
+    gb = torch.randn(N, 2 * C + 16, H, W, generator=g) * 0.5
+    st = torch.randn(N, 2 * C + 8, generator=g) * 0.5
+    dy = torch.randn(N, cout, H, W, generator=g)
+    res = torch.randn(N, C, H, W, generator=g)
+    if dtype == torch.bfloat16:
+        xn = xn.bfloat16().float(); w = w.bfloat16().float(); gb = gb.bfloat16().float(); dy = dy.bfloat16().float(); res = res.bfloat16().float()
+    geom = ops.ConvGeom(C, cout, 3, 1, 1)
+    xnd = nhwc(xn, C, dtype, dev)
+    wb = pack_bwd(w, C, cout, dtype, dev)
+    gbd = nhwc(gb, 2 * C + 16, dtype, dev)
+    std = st.to(dev)
+    dyd = nhwc(dy, cout, dtype, dev)
+    resd = nhwc(res, C, dtype, dev) if with_res else None
+    a_fwd, stats = ops.in_norm_fwd(xnd, C, gbd, 16, std, 8, ACT_LRELU, 0.2)
+    dgb1 = torch.zeros_like(gbd); dst1 = torch.zeros_like(std)
+    dx1 = ops.conv_dgrad_mat(geom, dyd, wb, xnd, C, stats, gbd, 16, std, 8, ACT_LRELU, 0.2, dgb1, 16, dst1, 8, res=resd)
+    # the two separate calls
+    dgb2 = torch.zeros_like(gbd); dst2 = torch.zeros_like(std)
+    d_mid = ops.conv_dgrad(geom, dyd, wb, tuple(xnd.shape), C)
+    dx2 = ops.in_bwd(d_mid, xnd, C, stats, gbd, 16, std, 8, ACT_LRELU, 0.2, dgb2, 16, dst2, 8, res=resd)
+    torch.cuda.synchronize()
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(dx1.float().cpu(), dx2.float().cpu().double()) < tol
+    assert rel_err(dgb1.float().cpu(), dgb2.float().cpu().double()) < tol
+    assert rel_err(dst1.cpu(), dst2.cpu().double()) < (1e-5 if dtype == torch.float32 else 2e-3)
+    # float64 autograd of norm -> modulate -> lrelu -> conv
+    xr = xn.double().requires_grad_(True); gbr = gb.double().requires_grad_(True); str_ = st.double().requires_grad_(True)
+    xh = F.instance_norm(xr, eps=1e-5)
+    gam = gbr[:, 16:16 + C] + str_[:, 8:8 + C][:, :, None, None]
+    bet = gbr[:, 16 + C:16 + 2 * C] + str_[:, 8 + C:8 + 2 * C][:, :, None, None]
+    y = F.conv2d(F.leaky_relu(xh * (1 + gam) + bet, 0.2), w.double(), padding=1)
+    y.backward(dy.double())
+    ref_dx = xr.grad + (res.double() if with_res else 0)
+    assert rel_err(nchw(dx1, C), ref_dx) < TOL[dtype]
+    assert rel_err(nchw(dgb1, 2 * C + 16)[:, 16:16 + 2 * C], gbr.grad[:, 16:16 + 2 * C]) < TOL[dtype]
+    assert rel_err(dst1.cpu()[:, 8:8 + 2 * C], str_.grad[:, 8:8 + 2 * C]) < (1e-5 if dtype == torch.float32 else 1e-2)
