@@ -23,7 +23,23 @@ struct LinArgs {
   int K, xin_pitch, dy_pitch, yact_pitch, dw_row, k_real;
 };
 
-typedef __attribute__((address_space(3))) volatile float lds_cvf;      // LDS, one ds_read_b32 per access
+// ---- how the staged tiles are read back from LDS --------------------------------------------------------------------
+// The tiles are padded to an odd pitch (65 / 17 floats) so that column reads spread over the banks; a row then starts
+// 0 / 4 / 8 / 12 bytes off 16-byte alignment depending on row % 4.  hipcc merges the unrolled k-loop's neighbouring loads
+// of such a row into ds_read2_b32 / ds_read2_b64 / ds_read_b128, and on MI355X those MULTI-DWORD reads of rows that are
+// 12 bytes off alignment (lanes 48..63 here) returned wrong data whenever an LDS-DMA kernel (buffer_load ... lds) shared the
+// CU (tests/tools/repro_lds.py with the S2P_LIN_LDS_MODE builds below).  The product build therefore
+// reads every element with lds_ld(): a relaxed atomic load, which the compiler may neither merge nor widen -- exactly one
+// ds_read_b32 per element (tests/test_host_logic.py::test_lds_access_widths checks the ISA), and keeps the odd pitch.
+// Diagnostic builds (build.sh diag -DS2P_LIN_LDS_MODE=n) restore the other forms for the repro:
+//   1: plain loads, pitch 65 (the code as first written)   2: plain loads, pitch 68 (every row 16-byte aligned)
+//   3: plain x-tile loads, lds_ld() for the w tile          4: lds_ld() for the x tile, plain w-tile loads
+#ifndef S2P_LIN_LDS_MODE
+#define S2P_LIN_LDS_MODE 0
+#endif
+constexpr int LIN_LD = S2P_LIN_LDS_MODE == 2 ? 68 : 65;
+__device__ __forceinline__ float lin_ld_x(const float* p) { return (S2P_LIN_LDS_MODE == 0 || S2P_LIN_LDS_MODE == 4) ? lds_ld(p) : *p; }
+__device__ __forceinline__ float lin_ld_w(const float* p) { return (S2P_LIN_LDS_MODE == 0 || S2P_LIN_LDS_MODE == 3) ? lds_ld(p) : *p; }
 
 __device__ __forceinline__ float lin_actgrad(float yv, int act, float slope) {
   return act == S2P_ACT_LRELU ? (yv > 0.f ? 1.f : slope) : (act == S2P_ACT_RELU ? (yv > 0.f ? 1.f : 0.f) : 1.f);
@@ -31,7 +47,7 @@ __device__ __forceinline__ float lin_actgrad(float yv, int act, float slope) {
 
 // y tile [64 rows][16 cols] of  x'[M][Kr] . W[N][Kr]^T,  x' = x * act'(xact) when xact != nullptr
 __device__ __forceinline__ void lin_gemm_tile(const LinArgs& a, int mb, int nb, int k0, int k1, float (&acc)[4], float* xs, float* ws) {
-  constexpr int KC = 64, LD = KC + 1;
+  constexpr int KC = 64, LD = LIN_LD;
   const int t = threadIdx.x, mq = t & 15, c = t >> 4;
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = 0.f;
@@ -73,23 +89,18 @@ __device__ __forceinline__ void lin_gemm_tile(const LinArgs& a, int mb, int nb, 
       for (int e = 0; e < 4; ++e) ws[r * LD + q * 4 + e] = v[e];
     }
     __syncthreads();
-    // LDS is read one dword at a time (volatile: no ds_read_b128 / ds_read2_b64).  Measured on MI355X: when one of the
-    // LDS-DMA conv kernels (buffer_load ... lds) shares the CU -- the state path runs on a side stream beside them -- the
-    // wide reads hipcc forms here (rows of 65 floats: every 4th row is 16-byte aligned) return wrong data in lanes 48..63:
-    // 30 of 30 results differ, ~1 % of a partial sum; dword reads: 0 of 30 (tests/tools/repro_lds.py, tests/test_model_gpu.py).
-    // Initialising M0 does not help (tried); kernels that use LDS-DMA themselves, the norm / thin / head kernels are unaffected.
-    const lds_cvf* xv = (const lds_cvf*)xs; const lds_cvf* wvp = (const lds_cvf*)ws;
+    // element-wise LDS reads: see lds_ld() above
 #pragma unroll 8
     for (int k = 0; k < KC; ++k) {
-      const float wv = wvp[c * LD + k];
+      const float wv = lin_ld_w(ws + c * LD + k);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = __builtin_fmaf(xv[(4 * mq + i) * LD + k], wv, acc[i]);
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_fmaf(lin_ld_x(xs + (4 * mq + i) * LD + k), wv, acc[i]);
     }
   }
 }
 
 __global__ __launch_bounds__(256) void lin_fwd_kernel(const LinArgs a) {
-  __shared__ float xs[64 * 65], ws[16 * 65];
+  __shared__ __attribute__((aligned(16))) float xs[64 * LIN_LD], ws[16 * LIN_LD];
   const int nb = blockIdx.x * 16, mb = blockIdx.y * 64, z = blockIdx.z;
   const int k0 = z * a.k_per_split, k1 = k0 + a.k_per_split < a.Kr ? k0 + a.k_per_split : a.Kr;
   float acc[4];
@@ -128,7 +139,8 @@ __global__ __launch_bounds__(256) void lin_splitk_reduce_kernel(const LinArgs a)
 
 // dW[N][K] += dpre^T x, db[N] += sum_m dpre   (dpre = dy * act'(y))
 __global__ __launch_bounds__(256) void lin_wgrad_kernel(const LinArgs a) {
-  __shared__ float xs[64 * 65], ws[64 * 17];
+  constexpr int LDX = LIN_LD, LDD = S2P_LIN_LDS_MODE == 2 ? 20 : 17;   // pitches of the x / dpre tiles (mode 2: 16-byte-aligned rows)
+  __shared__ __attribute__((aligned(16))) float xs[64 * LDX], ws[64 * LDD];
   const int t = threadIdx.x;
   // ---- wgrad tile: 16 outputs n x 64 inputs k; dpre staged [m][16], x staged [m][64]; thread = (4 k, 1 n) ----------
   const int kt_n = (a.K + 63) / 64;
@@ -146,7 +158,7 @@ __global__ __launch_bounds__(256) void lin_wgrad_kernel(const LinArgs a) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (m < a.M && k < a.K) v = *(const f32x4*)(a.xin + (size_t)m * a.xin_pitch + k);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) xs[r * 65 + q * 4 + e] = v[e];
+      for (int e = 0; e < 4; ++e) xs[r * LDX + q * 4 + e] = v[e];
     }
     {                                                      // dpre : 64 rows x 16 n
       const int r = t >> 2, q = t & 3;
@@ -161,15 +173,14 @@ __global__ __launch_bounds__(256) void lin_wgrad_kernel(const LinArgs a) {
         }
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) ds[r * 17 + q * 4 + e] = v[e];
+      for (int e = 0; e < 4; ++e) ds[r * LDD + q * 4 + e] = v[e];
     }
     __syncthreads();
     const int mlim = a.M - mb < 64 ? a.M - mb : 64;
-    const lds_cvf* xv = (const lds_cvf*)xs; const lds_cvf* dv = (const lds_cvf*)ds;        // dword LDS reads only (see lin_gemm_tile)
     for (int m = 0; m < mlim; ++m) {
-      const float d = dv[m * 17 + c];
+      const float d = lin_ld_w(ds + m * LDD + c);            // element-wise LDS reads: see lds_ld()
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = __builtin_fmaf(d, xv[m * 65 + 4 * kq + i], acc[i]);
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_fmaf(d, lin_ld_x(xs + m * LDX + 4 * kq + i), acc[i]);
       accb += d;
     }
   }

@@ -769,3 +769,32 @@ extern "C" int s2p_ensemble_head(const float* raw, int raw_pitch, const float* x
   S2P_CHECK_LAUNCH("ensemble_head_kernel");
   return 0;
 }
+
+#ifdef S2P_DIAG_BUILD
+// Diagnostics build only: an LDS "canary".  Every workgroup (256 threads) fills `words` dwords of LDS with a pattern, then for
+// `spins` rounds sleeps and re-reads all of it with single-dword reads.  A word that no longer holds its pattern was overwritten
+// by SOMEBODY ELSE (the workgroup itself never writes again): out[0] counts them, out[1 + 2 i] / out[2 + 2 i] record the
+// dword offset and the value found for the first few (tests/tools/repro_canary.py runs it beside the LDS-DMA kernels).
+__global__ __launch_bounds__(256) void lds_canary_kernel(int words, int spins, unsigned* out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned cz[];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < words; i += 256) cz[i] = 0xA5000000u ^ (unsigned)i;
+  __syncthreads();
+  for (int s = 0; s < spins; ++s) {
+    __builtin_amdgcn_s_sleep(64);
+    for (int i = tid; i < words; i += 256) {
+      const unsigned v = __hip_atomic_load(&cz[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (v != (0xA5000000u ^ (unsigned)i)) {
+        const unsigned k = atomicAdd(out, 1u);
+        if (k < 16) { out[1 + 2 * k] = (unsigned)i; out[2 + 2 * k] = v; }
+        cz[i] = 0xA5000000u ^ (unsigned)i;               // re-arm
+      }
+    }
+  }
+}
+extern "C" int s2p_diag_lds_canary(int blocks, int words, int spins, unsigned* out, void* stream) {
+  hipLaunchKernelGGL(lds_canary_kernel, dim3(blocks), dim3(256), (size_t)words * 4, (hipStream_t)stream, words, spins, out);
+  S2P_CHECK_LAUNCH("lds_canary_kernel");
+  return 0;
+}
+#endif

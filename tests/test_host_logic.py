@@ -160,3 +160,44 @@ def test_conv_geometry_matches_torch():
         y = F.conv_transpose2d(x, torch.zeros(cin, cout, k, k), stride=s, padding=p, output_padding=op) if tr else \
             F.conv2d(x, torch.zeros(cout, cin, k, k), stride=s, padding=p)
         assert g.out_hw(H, H) == tuple(y.shape[2:])
+
+
+def test_lds_access_widths():
+    """ISA-level guard for the LDS co-residency hazard, no GPU needed: disassemble every gfx950 kernel of
+    libs2p_hip.so and check which LDS read instructions it contains.
+      * the state path's linear kernels must read LDS with single-dword instructions only (the merged reads hipcc would
+        form on their weight tile are the ones that returned wrong data beside LDS-DMA kernels);
+      * every OTHER kernel that has multi-dword LDS reads and does not itself stage through LDS-DMA must be on the list below,
+        i.e. must have been run as a victim in tests/test_model_gpu.py::test_small_kernels_are_undisturbed_by_lds_dma_kernels...
+        -- a new kernel, or a compiler / code change that starts merging LDS reads in a kernel that is not listed, fails here
+        and has to be added to that GPU test first."""
+    import re
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import isa_audit
+    if not os.path.exists(isa_audit.LLVM + "/llvm-objdump"):
+        pytest.skip("llvm-objdump not available")
+    a = isa_audit.audit(_lib._SO)
+    names = isa_audit.demangle(list(a))
+    assert len(a) > 60, "disassembly found too few kernels"
+    wide = re.compile(r"^ds_read(2|2st64)?_(b32|b64|b96|b128)$")
+    def wide_reads(v):
+        return {op: n for op, n in v["ds"].items() if wide.match(op) and op != "ds_read_b32"}
+    lin = [k for k in a if re.search(r"lin_(fwd|wgrad)_kernel", names[k])]
+    assert len(lin) == 2, [names[k] for k in lin]
+    for k in lin:
+        assert not wide_reads(a[k]), (names[k], dict(a[k]["ds"]))
+        assert a[k]["ds"].get("ds_read_b32", 0) >= 40
+    # non-DMA kernels that are allowed to contain multi-dword LDS reads: each is a victim of the GPU co-residency test
+    verified = [r"in_(reduce|apply|fused_fwd|fused_bwd)_kernel", r"thin_(fwd|cin_fwd|rows_fwd|tiled_fwd|tiled_wgrad)_kernel",
+                r"head_(fwd|wgrad|wgrad_reduce)_kernel", r"conv_part_reduce_kernel", r"wgrad_part_reduce_kernel",
+                r"s2p_partial_reduce_kernel", r"(hinge|hinge_strided|l1_loss|l1_multi)_kernel", r"image_metrics_kernel",
+                r"channel_sum_kernel", r"lin_splitk_reduce_kernel",
+                # MFMA kernels of the fp32 / thin-channel paths: register-staged 16-byte-aligned tiles read by their own waves
+                r"conv_(gather|fast)_kernel", r"wgrad_kernel"]
+    unlisted = []
+    for k, v in a.items():
+        if v["lds_dma"] or k in lin or not wide_reads(v):
+            continue
+        if not any(re.search(pat, names[k]) for pat in verified):
+            unlisted.append((names[k], wide_reads(v)))
+    assert not unlisted, unlisted

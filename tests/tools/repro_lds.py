@@ -34,9 +34,13 @@ loads = {
 }
 side = torch.cuda.Stream()
 ref = None
+ITERS = int(os.environ.get("REPRO_ITERS", "30"))
+ONLY = os.environ.get("REPRO_ONLY", "")
 for name, fn in loads.items():
+    if ONLY and not any(k in name for k in ONLY.split(",")):
+        continue
     bad = 0
-    for it in range(30):
+    for it in range(ITERS):
         dw = torch.zeros(N * K, device="cuda"); db = torch.zeros(N, device="cuda")
         torch.cuda.synchronize()
         for _ in range(6):
@@ -47,4 +51,4 @@ for name, fn in loads.items():
         if ref is None:
             ref = dx.clone()
         bad += int(not torch.equal(dx, ref))
-    print("%-40s: %2d of 30 results differ from the quiet result" % (name, bad), flush=True)
+    print("%-40s: %2d of %d results differ from the quiet result" % (name, bad, ITERS), flush=True)
