@@ -136,8 +136,36 @@ def cpu_baseline(args, state_dim):
                        "after 1 warm-up, torch fp32 on host cores" % (B, args.size, args.size, args.cpu_steps))
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves.  The parent has not touched the GPU (device_count
+    does not initialise it) and never execs: torch.distributed.run is a fresh child process whose one JSON line and exit code
+    are relayed."""
+    import socket
+    import subprocess
+    if not args.share_gpu and torch.cuda.device_count() < args.gpus:
+        print("bench.py --gpus %d: only %d HIP device(s) visible" % (args.gpus, torch.cuda.device_count()), file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC only on this pool (RCCL / cross-process sharing)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    elif r.returncode == 0:
+        print("bench.py: the ranks printed no result line", file=sys.stderr)
+        return 3
+    return r.returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     # stdout carries exactly ONE JSON line (driver contract).  Native libraries write there too (RCCL prints a version banner
     # on communicator creation): point fd 1 at stderr for the run and keep the real stdout for the result line.
     sys.stdout.flush()
@@ -147,9 +175,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE %d (launch with torch.distributed.run for N>1)" % (args.gpus, world),
-                  file=sys.stderr)
+        raise RuntimeError("--gpus %d but the launcher started WORLD_SIZE %d ranks" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a HIP device: the S2P hot path has no CPU fallback")
     if args.share_gpu:
@@ -231,6 +257,7 @@ def main():
 
     # ---- roofline leg: one instrumented eager step, events around every MFMA conv launch --------------------
     roofline = None
+    comm_ms = []
     if not args.no_roofline:
         # every rank runs the instrumented step (it contains the gradient all-reduces); rank 0 reports
         # three instrumented steps; a launch's time is the MEDIAN of its three samples (one sample can be lengthened by a
@@ -239,9 +266,13 @@ def main():
         reps = []
         for _ in range(3):
             ops.PROFILE = []
+            trainer.comm_events = [] if dp.active else None
             eager_step()
             trainer.sync(); torch.cuda.synchronize()
             reps.append(ops.PROFILE)
+            if dp.active:
+                comm_ms.append(sum(e0.elapsed_time(e1) for e0, e1 in trainer.comm_events))
+        trainer.comm_events = None
         ops.SERIALIZE = bool(args.serial_streams)
         ops.PROFILE = None
         all_recs = reps[0]
@@ -312,14 +343,20 @@ def main():
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_traffic.json")))
             if cands:
                 tj = json.load(open(cands[-1]))
-                want_grid = str(((args.batch * (args.size // 4) ** 2 + 127) // 128) * 2 * 256)
+                want_grid = str(args.batch * 4 * 512)                 # plane-resident conv: one 512-thread workgroup per (image, 64-channel slab)
+                meta = tj.get("_meta", {})
+                from s2p_amd import _lib as _l
+                if meta.get("s2p_version") != _l.lib().s2p_version():
+                    raise RuntimeError("%s was measured on library version %s, this run loads %s: not reported" % (
+                        os.path.basename(cands[-1]), meta.get("s2p_version"), _l.lib().s2p_version()))
                 for k, v in tj.items():
-                    if k.startswith("conv_halo_kernel") and ("grid %s " % want_grid) in k and "hbm_read_bytes" in v:
+                    if k.startswith("conv_plane_kernel<7, 22, 0, 0>") and ("grid %s " % want_grid) in k and "hbm_read_bytes" in v:
                         traffic = int(v["hbm_read_bytes"] + v["hbm_write_bytes"])          # HBM bytes per launch of the dominant kernel
                         traffic_detail = dict(hbm_read_mb=round(v["hbm_read_bytes"] / 1e6, 2), hbm_write_mb=round(v["hbm_write_bytes"] / 1e6, 2),
                                        algorithmic_mb=round((args.batch * (args.size // 4) ** 2 * 256 * 2 * 2 + 256 * 2304 * 2) / 1e6, 2),
                                        mfma_busy_share=round(v.get("mfma_util", 0.0), 4), launches_profiled=v.get("launches"),
-                                       source=os.path.relpath(cands[-1], ROOT) + " :: " + k)
+                                       source=os.path.relpath(cands[-1], ROOT) + " :: " + k, commit=meta.get("commit"),
+                                       s2p_version=meta.get("s2p_version"))
                         break
         except Exception as e:      # evidence file unreadable: report null rather than fail the bench
             print("[bench] traffic: %s" % e, file=sys.stderr)
@@ -334,6 +371,7 @@ def main():
                         by_kind={k: dict(gflop=round(v[0] / 1e9, 1), ms=round(v[1], 3), launches=v[2],
                                          tflops=round(v[0] / (v[1] * 1e-3) / 1e12, 2)) for k, v in by_kind.items()})
 
+    devices = sorted(set(dp.all_gather_ints(torch.cuda.current_device()))) if dp.active else None      # (a collective: every rank)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, opt.state_dim)
@@ -354,6 +392,14 @@ def main():
                        "vgg_weights": "seeded stand-in (ImageNet weights unobtainable offline)"},
             "roofline": roofline, "cpu_baseline": cpu, "losses": {k: round(v, 4) for k, v in losses.items()},
         }
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            # what the ranks actually ran on: backend ("nccl" = RCCL on ROCm), the size of the group the collectives used, and the
+            # time the compute stream spent WAITING for the communication stream in an instrumented eager step (events around
+            # the two join points: end of the G exchange, first use of D in the next G step)
+            out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                  "devices": devices,
+                                  "exposed_comm_ms_per_step": round(sorted(comm_ms)[len(comm_ms) // 2], 3) if comm_ms else None}
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     import torch.distributed as dist

@@ -7,7 +7,7 @@ requires_grad=True whose only job is to make autograd call the node's backward.
 """
 import torch
 
-from .. import ops
+from .. import ops, stepgraph
 from .._lib import chunk_elems
 
 
@@ -98,7 +98,7 @@ def vgg_real_prefetch(model, real_image, dt, ce):
     side stream while the generator forward runs on the main stream.  Returns the handle _GLossNode consumes."""
     main = torch.cuda.current_stream()
     vs = _vgg_stream(model)
-    vs.wait_stream(main)
+    stepgraph.fork(vs, main)
     real_image.record_stream(vs)
     with torch.cuda.stream(vs):
         real_nhwc = ops.nchw_to_nhwc(real_image, dt, ce)
@@ -134,7 +134,7 @@ def dreal_pass(model, prev_image, real_image, on_side):
     main = torch.cuda.current_stream()
     side = _side(model, "_dreal_side") if on_side else main
     if on_side:
-        side.wait_stream(main)
+        stepgraph.fork(side, main)
         prev_image.record_stream(side); real_image.record_stream(side)
     with torch.cuda.stream(side):
         xr = _build_d_half(model, prev_image, image_nchw=real_image)
@@ -185,7 +185,7 @@ class _GLossNode(torch.autograd.Function):
         if not opt.no_vgg_loss:
             from .networks.loss import VGG_WEIGHTS
             if vgg_on_side:
-                vs.wait_stream(main)
+                stepgraph.fork(vs, main)
                 fake.record_stream(vs); losses.record_stream(vs); real_nhwc.record_stream(vs)
             with torch.cuda.stream(vs):
                 if pre is not None:
@@ -254,7 +254,7 @@ class _GLossNode(torch.autograd.Function):
         if ctx.vctx is not None:                # VGG backward on its side stream, under the discriminator backward
             vs = _vgg_stream(model) if ctx.vgg_on_side else main
             if ctx.vgg_on_side:
-                vs.wait_stream(main)
+                stepgraph.fork(vs, main)
             with torch.cuda.stream(vs):
                 dv = model.vgg.bwd_nhwc(ctx.vctx, ctx.tap_grads, N)
             if ctx.vgg_on_side:
@@ -308,7 +308,7 @@ class _DStepNode(torch.autograd.Function):
         if cache is not None and (not DREAL_REUSE or cache["key"] != _dreal_key(model, prev_image, real_image)):
             cache = None
         if use_side:
-            side.wait_stream(main)
+            stepgraph.fork(side, main)
             for t in (prev_image, real_image, losses):
                 t.record_stream(side)
         with torch.cuda.stream(side):

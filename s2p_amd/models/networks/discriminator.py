@@ -10,7 +10,7 @@ import os
 import torch
 import torch.nn as nn
 
-from ... import ops
+from ... import ops, stepgraph
 from ..._lib import ACT_LRELU, ACT_NONE, EPI_ADD, EPI_MUL_ACTGRAD, EPI_STORE
 from ...ops import ConvGeom
 from .base_network import BaseNetwork
@@ -158,7 +158,7 @@ class MultiscaleDiscriminator(BaseNetwork):
             xs.append(ops.avgpool_fwd(xs[-1]))
         result, ctx = [None] * self.num_D, [None] * self.num_D
         if side is not main:
-            side.wait_stream(main)
+            stepgraph.fork(side, main)
         with torch.cuda.stream(side):
             for i in range(1, self.num_D):
                 if side is not main:
@@ -194,7 +194,7 @@ class MultiscaleDiscriminator(BaseNetwork):
 
         dx_next = None
         if fork:
-            side.wait_stream(main)
+            stepgraph.fork(side, main)
             for i in range(1, self.num_D):                     # made on main or on a forward lane, read on `side`
                 x, saved = ctx[i]
                 for tup in saved:

@@ -14,7 +14,7 @@ import os
 import torch
 import torch.nn as nn
 
-from ... import ops
+from ... import ops, stepgraph
 from ..._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, EPI_ADD, EPI_MUL_ACTGRAD, chunk_elems
 from ...ops import ConvGeom, pad_to
 from .base_network import BaseNetwork
@@ -200,7 +200,7 @@ class S2PGenerator(BaseNetwork):
         # convs and the encoder, so it runs on a side stream and overlaps them (the fork/join is captured by hipGraph).
         main = torch.cuda.current_stream()
         side = self._side_stream() if STATE_SIDE_FWD else main
-        side.wait_stream(main)
+        stepgraph.fork(side, main)
         with torch.cuda.stream(side):
             # dedicated small-M fp32 kernels (csrc/linear_small.hip): one ~4 us launch per layer
             pe_dim = self.state_dim * (1 + 2 * self.L_oct)
@@ -220,7 +220,7 @@ class S2PGenerator(BaseNetwork):
         hq, wq = H >> self.n_down, W >> self.n_down
         cs = self._cond_stream() if (COND_SIDE and not ops.SERIALIZE) else main
         if cs is not main:
-            cs.wait_stream(main)
+            stepgraph.fork(cs, main)
             img.record_stream(cs)
         with torch.cuda.stream(cs):
             seg = ops.resize_nearest(img, hq, wq)
@@ -340,7 +340,7 @@ class S2PGenerator(BaseNetwork):
                 if extra is not None:
                     extra()
                 return
-            ws.wait_stream(main)
+            stepgraph.fork(ws, main)
             for _, x, dy in jobs:
                 x.record_stream(ws); dy.record_stream(ws)
             with torch.cuda.stream(ws):
@@ -392,14 +392,14 @@ class S2PGenerator(BaseNetwork):
         # backward of the image-conditioning branch on its side stream, concurrent with the encoder backward below
         cs = self._cond_stream() if (COND_SIDE and not ops.SERIALIZE) else main
         if cs is not main:
-            cs.wait_stream(main)
+            stepgraph.fork(cs, main)
             dgb_all.record_stream(cs); actv.record_stream(cs)
         with torch.cuda.stream(cs):
             d_actv = L["gb"].dgrad(dgb_all, actv.shape, aux=actv, epi=EPI_MUL_ACTGRAD, aux_act=ACT_RELU)
             L["shared"].wgrad(seg, d_actv)
         # state path backward on the side stream, overlapped with the encoder backward below
         side = self._side_stream() if STATE_SIDE_BWD else main
-        side.wait_stream(main)
+        stepgraph.fork(side, main)
         dst_all.record_stream(side)
         with torch.cuda.stream(side):
             hs = ctx["hs"]

@@ -74,6 +74,16 @@ class DataParallelGroup:
         if self.active:
             dist.barrier(group=self.group)
 
+    def all_gather_ints(self, value):
+        """[value of rank 0, value of rank 1, ...] (bench.py: which device every rank ran on)."""
+        if not self.active:
+            return [int(value)]
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+        out = [torch.zeros_like(t) for _ in range(self.world_size)]
+        dist.all_gather(out, t, group=self.group)
+        return [int(x.item()) for x in out]
+
     def max_over_ranks(self, value):
         if not self.active:
             return value

@@ -18,8 +18,24 @@ serves eager training, warm-up and capture.  All segments share one memory pool:
 and consumed in a later one (activations saved for backward, gradient buffers) keep their addresses across replays.
 """
 import gc
+import warnings
 
 import torch
+
+_ACTIVE = None      # the StepGraph that is capturing right now (one per process)
+
+
+def fork(side, main=None):
+    """`side.wait_stream(main)` for a side stream that is about to receive work, with the one rule hipGraph capture imposes
+    on this code base checked: while a step is being captured every fork must start from the CAPTURING stream.  A side stream
+    forked from another side stream made hipStreamEndCapture abort the process (ROCm 7.2) -- here it is a
+    Python error at the fork instead."""
+    main = main if main is not None else torch.cuda.current_stream()
+    sg = _ACTIVE
+    if sg is not None and sg.capturing and side != main and main != sg._stream:
+        raise RuntimeError("stream fork from a side stream while a hipGraph segment is being captured: fork from the capturing "
+                           "stream only (run the forking code on the main stream, or join the outer side stream first)")
+    side.wait_stream(main)
 
 
 class StepGraph:
@@ -29,6 +45,7 @@ class StepGraph:
         self._capturing = False
         self._cur = None
         self._pool = None
+        self._stream = None        # the stream the segments are captured on
         self.captured = False
 
     # ---- used by the step function ---------------------------------------------------------------------
@@ -51,8 +68,17 @@ class StepGraph:
         self._cur = g
 
     def _end_segment(self):
-        self._cur.capture_end()
-        self.seq.append(("graph", self._cur))
+        # two cuts back to back (or a cut as the last thing of the step) leave a segment without a single node: it is dropped,
+        # so a replay does not pay a graph launch + host round trip for nothing
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            self._cur.capture_end()
+        empty = any("graph is empty" in str(x.message).lower() for x in w)
+        for x in w:
+            if "graph is empty" not in str(x.message).lower():
+                warnings.warn_explicit(x.message, x.category, x.filename, x.lineno)
+        if not empty:
+            self.seq.append(("graph", self._cur))
         self._cur = None
 
     def capture(self, step_fn):
@@ -63,16 +89,20 @@ class StepGraph:
         torch.cuda.synchronize()
         gc.collect()
         self._pool = torch.cuda.graph_pool_handle()
+        global _ACTIVE
         stream = torch.cuda.Stream()
         stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(stream):
             self._capturing = True
+            self._stream = stream
+            _ACTIVE = self
             try:
                 self._begin_segment()
                 step_fn()
                 self._end_segment()
             finally:
                 self._capturing = False
+                _ACTIVE = None
         torch.cuda.current_stream().wait_stream(stream)
         torch.cuda.synchronize()
         self.captured = True

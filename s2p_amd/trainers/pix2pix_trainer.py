@@ -32,6 +32,8 @@ class Pix2PixTrainer:
         self.generated = None
         self.seg = None
         self._eD = None                 # event: D's all-reduce + Adam + repack of the previous step are done
+        self._eD_waited = True          # ... and whether the main stream has waited for it since it was recorded
+        self.comm_events = None         # a list: (event, event) pairs around every wait of the compute stream for the exchange
         self.dp = parallel.DataParallelGroup.from_env()
         if opt.isTrain:
             self.dp.broadcast_store(self.pix2pix_model.netG.store)
@@ -56,11 +58,23 @@ class Pix2PixTrainer:
         else:
             action()
 
+    def _timed_wait(self, action):
+        """`action` makes the current stream wait for the communication stream; with `comm_events` set (bench.py's instrumented
+        step) the wait is bracketed by two events on the current stream: their distance is the EXPOSED communication time."""
+        if self.comm_events is None:
+            return action()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        action()
+        e1.record()
+        self.comm_events.append((e0, e1))
+
     def _wait_D_update(self):
         def act():
             if self._eD is not None:
-                torch.cuda.current_stream().wait_event(self._eD)
+                self._timed_wait(lambda: torch.cuda.current_stream().wait_event(self._eD))
         self._cut(act)
+        self._eD_waited = True
 
     def _allreduce_G_tail(self):
         net = self.pix2pix_model.netG
@@ -73,7 +87,7 @@ class Pix2PixTrainer:
 
         def act():
             self.dp.all_reduce_async(head)
-            self.dp.join()
+            self._timed_wait(self.dp.join)
         self._cut(act)
 
     def _finish_D_async(self):
@@ -89,6 +103,7 @@ class Pix2PixTrainer:
             ev = torch.cuda.Event()
             ev.record(comm)
         self._eD = ev
+        self._eD_waited = False
 
     # ---- the two steps ---------------------------------------------------------------------------------------------------
     def run_generator_one_step(self, data):
@@ -105,6 +120,11 @@ class Pix2PixTrainer:
         self.generated = generated
 
     def run_discriminator_one_step(self, data):
+        if self.dp.active and not self._eD_waited:
+            # the previous D step's all-reduce + Adam + repack may still be running on the communication stream: they read
+            # netD.store.grad and rewrite the packed weights, which zero_grad / the forward below touch.  Two D steps in a row
+            # (--D_steps_per_G > 1) get here un-waited; after a G step the hook in the G-loss node has already waited.
+            self._wait_D_update()
         self.optimizer_D.zero_grad()
         d_losses = self.pix2pix_model(data, mode="discriminator")
         self._backward(d_losses)

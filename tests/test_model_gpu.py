@@ -650,6 +650,41 @@ def test_train_cli_epochs_checkpoint_and_resume(hip_device, tmp_path, graph):
                     str(tmp_path), "--continue_train"])
 
 
+def test_train_cli_graph_replay_matches_eager(hip_device, tmp_path):
+    """train.py --hip_graph trains on every batch exactly once: after the same two epochs the step counters equal the eager
+    run's and the weights agree (the kernels and their order are the same; ADVICE.md round 2: the warm-up batch used to be
+    trained on twice).  A checkpoint whose flat layout signature differs is refused."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import train
+    out = {}
+    for mode in ("eager", "graph"):
+        d = os.path.join(str(tmp_path), mode)
+        args = ["--env_type=cheetah", "--dataroot=" + os.path.join(root, "datasets"), "--netG=s2p", "--batchSize=2", "--gpu_ids=0",
+                "--checkpoints_dir", d, "--save_epoch_freq", "2", "--print_freq", "100", "--no_vgg_loss", "--niter", "2"]
+        torch.manual_seed(1234)
+        train.main(args + (["--hip_graph"] if mode == "graph" else []))
+        out[mode] = torch.load(os.path.join(d, "cheetah_2.pth"), map_location="cpu")
+    e, g = out["eager"], out["graph"]
+    assert e["iters_done"] == g["iters_done"] and int(e["optG"]["step"]) == int(g["optG"]["step"]) == e["iters_done"]
+    assert int(e["optD"]["step"]) == int(g["optD"]["step"])
+    for net in ("netG", "netD"):
+        for k in e[net]:
+            a, b = e[net][k].float(), g[net][k].float()
+            assert float((a - b).norm()) <= 1e-4 * float(a.norm()) + 1e-7, (net, k)
+    assert e["optG"]["layout"] == g["optG"]["layout"] and len(e["optG"]["layout"]) == 16
+    # a checkpoint from another flat layout must not be applied silently
+    from s2p_amd.options.train_options import TrainOptions
+    from s2p_amd.trainers.pix2pix_trainer import Pix2PixTrainer
+    bad = dict(e); bad["optG"] = dict(e["optG"], layout="0" * 16)
+    torch.save(bad, os.path.join(str(tmp_path), "eager", "cheetah_latest.pth"))
+    opt = TrainOptions().parse(["--env_type=cheetah", "--gpu_ids=0", "--batchSize=2", "--checkpoints_dir", os.path.join(str(tmp_path), "eager"),
+                                "--continue_train"], quiet=True)
+    with pytest.raises(RuntimeError, match="flat parameter layout"):
+        Pix2PixTrainer(opt)
+
+
 def test_small_kernels_are_undisturbed_by_lds_dma_kernels_on_the_same_cus(hip_device, tmp_path):
     """Regression for a co-residency hazard found on MI355X: while an LDS-DMA conv kernel
     (`buffer_load ... lds`) runs on another stream and shares CUs with them, the state path's linear kernels returned wrong

@@ -19,7 +19,7 @@ def main(args=None):
     it = trainer.pix2pix_model.iters_done                 # > 0 when resuming with --continue_train
     # --hip_graph: the G+D step is captured once into hipGraph segments (s2p_amd/stepgraph.py) and replayed; each batch is
     # copied into static device buffers first.  The capture bakes the learning rate in, so it is redone when the rate changes.
-    sg, static, captured_lr = None, None, None
+    sg, static, captured_lr, warned_graph = None, None, None, False
     for epoch in range(trainer.first_epoch, total_epochs + 1):
         if hasattr(dl.sampler, "set_epoch"):
             dl.sampler.set_epoch(epoch)
@@ -33,21 +33,24 @@ def main(args=None):
                     static = {k: data[k].to(dev, torch.float32).contiguous().clone() for k in ("prev_image", "state", "image")}
                 for k in static:
                     static[k].copy_(data[k], non_blocking=True)
+                trained = False
                 if sg is None or captured_lr != trainer.old_lr:
                     def train_step():
                         trainer.run_generator_one_step(static)
                         trainer.run_discriminator_one_step(static)
                     if sg is None:
-                        train_step()                       # one eager step first (allocator / library warm-up)
-                        it += 1
-                        for k in static:
-                            static[k].copy_(data[k], non_blocking=True)
+                        train_step()                       # the very first batch is trained on eagerly (allocator / library warm-up)
+                        trained = True
                     sg = StepGraph()
                     trainer.seg = sg
-                    sg.capture(train_step)                 # kernels are only RECORDED during capture ...
+                    sg.capture(train_step)                 # kernels are only RECORDED during capture: no update happens here
                     captured_lr = trainer.old_lr
-                sg.replay()                                # ... so the batch is trained on by the replay, also right after a capture
+                if not trained:
+                    sg.replay()                            # every other batch (also the one a re-capture saw) is trained on by a replay
             else:
+                if opt.hip_graph and not warned_graph and trainer.dp.rank == 0:
+                    print("warning: --hip_graph is ignored with --D_steps_per_G %d (the captured step is one G + one D step)" % opt.D_steps_per_G)
+                    warned_graph = True
                 if i % opt.D_steps_per_G == 0:
                     trainer.run_generator_one_step(data)
                 trainer.run_discriminator_one_step(data)
