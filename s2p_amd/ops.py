@@ -397,6 +397,9 @@ def nchw_to_nhwc(x, dtype, pitch, out=None, c_off=0, zero_pad=True):
 def nhwc_to_nchw(x, C, c_off=0, out=None, accumulate=False):
     N, H, W, xp = x.shape
     y = out if out is not None else torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
+    if not y.is_contiguous() or tuple(y.shape) != (N, C, H, W) or y.dtype != torch.float32:
+        raise ValueError("nhwc_to_nchw: `out` must be a contiguous fp32 [N,C,H,W] tensor, got shape %s strides %s %s" % (
+            tuple(y.shape), y.stride(), y.dtype))
     check(lib().s2p_nhwc_to_nchw(dtype_id(x.dtype), ptr(x), xp, c_off, N, C, H, W, ptr(y), int(accumulate), stream()),
           "s2p_nhwc_to_nchw")
     return y

@@ -1,5 +1,5 @@
 """Child process of tests/test_dp_gpu.py: one data-parallel rank running ONE real Pix2PixTrainer G step + D step.
-Usage: python dp_worker.py RANK WORLD PORT OUTFILE [rccl]   (all ranks share GPU 0; gloo carries the collectives, so the
+Usage: python dp_worker.py RANK WORLD PORT OUTFILE [rccl | d2]   (DP_B: global batch, default 4; all ranks share GPU 0; gloo carries the collectives, so the
 N>1 code path of trainer / parallel.py / FlatAdam runs on a one-GPU box exactly as it does over RCCL.  With `rccl` and
 WORLD 1 the exchange path runs over a one-rank RCCL group instead: S2P_FORCE_DP, backend 'nccl')."""
 import os
@@ -13,6 +13,7 @@ def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     rccl = len(sys.argv) > 5 and sys.argv[5] == "rccl"
+    two_d = len(sys.argv) > 5 and sys.argv[5] == "d2"       # --D_steps_per_G 2: a second D step right behind the first
     if rccl:
         assert world == 1
         os.environ["S2P_FORCE_DP"] = "1"                    # DataParallelGroup.from_env makes the one-rank 'nccl' group
@@ -22,7 +23,7 @@ def main():
     from s2p_amd.trainers.pix2pix_trainer import Pix2PixTrainer
     if world > 1:
         dist.init_process_group(backend="gloo")
-    B = 4                                                   # global batch; each rank takes B / world samples
+    B = int(os.environ.get("DP_B", "4"))                    # global batch; each rank takes B / world samples
     per = B // world
     opt = TrainOptions().parse(["--env_type", "cheetah", "--batchSize", str(per), "--precision", "bf16", "--gpu_ids", "0",
                                 "--checkpoints_dir", os.path.dirname(out)], quiet=True)
@@ -46,6 +47,10 @@ def main():
     model.netG.store.master.copy_(w0.to(model.netG.store.master.device))
     model.netG.store.repack()
     tr.run_discriminator_one_step(data)
+    if two_d:
+        # the first D step's all-reduce + Adam + repack are still running on the communication stream: the second step's
+        # zero_grad / forward must wait for them
+        tr.run_discriminator_one_step(data)
     tr.sync()                                               # D's all-reduce + Adam run on the communication stream
     gD = (model.netD.store.grad * tr.optimizer_D.grad_scale).detach().cpu().clone()
     torch.cuda.synchronize()

@@ -18,11 +18,12 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _run(world, tmp, extra=()):
+def _run(world, tmp, extra=(), batch=4):
     port = str(_free_port())
-    outs = [os.path.join(tmp, "w%d_r%d%s.pt" % (world, r, "_".join(extra))) for r in range(world)]
+    outs = [os.path.join(tmp, "w%d_b%d_r%d%s.pt" % (world, batch, r, "_".join(extra))) for r in range(world)]
+    env = dict(os.environ, DP_B=str(batch))
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), str(r), str(world), port, outs[r], *extra],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(world)]
     for p in procs:
         try:
             log, _ = p.communicate(timeout=420)
@@ -126,3 +127,43 @@ def test_bench_segmented_graphs_over_rccl_one_rank(hip_device, tmp_path):
     dp = json.loads(lines[0])
     assert dp["config"]["hip_graph"] is True and dp["config"]["graph_segments"] >= 4, dp["config"]
     assert all(v == v and abs(v) < 1e4 for v in dp["losses"].values()), dp["losses"]
+
+
+def test_four_ranks_one_sample_each_equal_one_rank_batch_four(hip_device, tmp_path):
+    """world = 4, ONE sample per rank (the smallest shard the path can take) against 1 rank x batch 4: 1/4 folded into Adam,
+    four parameter broadcasts, the early tail all-reduce with four contributors.  (A one-GPU box admits at most 6 processes on
+    the card, this pytest process included: 4 ranks is what fits; the world = 8 arithmetic of parallel.py runs on the CPU in
+    tests/test_parallel_gloo.py.)"""
+    single = _run(1, str(tmp_path))[0]
+    rs = _run(4, str(tmp_path))
+    assert all(r["world"] == 4 and r["active"] for r in rs)
+    for r in rs[1:]:
+        assert torch.equal(r["w0"], rs[0]["w0"])
+        for k in ("gG", "gD", "wG", "wD"):
+            assert torch.equal(r[k], rs[0][k]), k                # ranks bitwise in lock-step
+    assert torch.equal(rs[0]["w0"], single["w0"])
+    for k in ("gG", "gD"):
+        err = float((rs[0][k].double() - single[k].double()).norm() / single[k].double().norm())
+        print("4 ranks x 1 vs single-process %s: rel-L2 %.3e" % (k, err))
+        assert err < 1e-5, (k, err)
+    for k, v in single["losses"].items():
+        avg = sum(r["losses"][k] for r in rs) / 4
+        assert abs(avg - v) <= 1e-4 * max(abs(v), 1e-2), (k, avg, v)
+
+
+def test_two_discriminator_steps_in_a_row_with_the_exchange_on(hip_device, tmp_path):
+    """--D_steps_per_G 2 with data parallelism: the second D step starts while the first one's all-reduce +
+    Adam + weight repack are still on the communication stream; it must wait for them before zero_grad / its forward.  A race
+    there wipes gradients mid-reduce or reads half-repacked weights: gross errors.  2 ranks x batch 2 against 1 rank x batch 4,
+    both doing G, D, D."""
+    single = _run(1, str(tmp_path), extra=("d2",))[0]
+    r0, r1 = _run(2, str(tmp_path), extra=("d2",))
+    for k in ("gD", "wD", "gG"):
+        assert torch.equal(r0[k], r1[k]), k
+    # the second D step's gradient is taken at weights that moved by one sign-like Adam step (see dp_worker.py): the two runs
+    # agree to the accuracy those weights agree, far inside what a race would do
+    err = float((r0["gD"].double() - single["gD"].double()).norm() / single["gD"].double().norm())
+    print("two D steps, DP vs single-process gD: rel-L2 %.3e" % err)
+    assert err < 2e-2, err
+    dw = float((r0["wD"].double() - single["wD"].double()).abs().max())
+    assert dw <= 2.5 * single["lrD"], (dw, single["lrD"])           # two Adam steps: every weight moved by at most ~2 lr in both runs

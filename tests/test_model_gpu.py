@@ -13,6 +13,7 @@ tolerances (measured: median 1.5e-2, worst real parameter 5e-2; the structurally
 InstanceNorm carry bf16 rounding noise of 4e-3 of a typical gradient, i.e. 8e-2 against the floor used here).
 fp32 forward: 1e-5 relative L2 (north_star asks 1e-3)."""
 import os
+import re
 
 import pytest
 import torch
@@ -32,18 +33,26 @@ def rel_l2(a, b):
     return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-300))
 
 
-def grad_errors(named_hip, ref64, floor_frac=0.05):
-    """Per-parameter relative L2 error of the HIP gradients against the float64 oracle.  Gradients that are
-    structurally zero (a conv bias in front of an InstanceNorm: exactly 0 in exact arithmetic, rounding noise in any
-    finite precision) are compared against a floor tied to the typical gradient magnitude, not their own norm."""
+STRUCTURAL_ZERO = re.compile(r"^blocks\.\d+\.conv_0\.bias$")
+
+
+def grad_errors(named_hip, ref64):
+    """Per-parameter relative L2 error of the HIP gradients against the float64 oracle.
+    The bias of a conv that feeds an InstanceNorm directly (blocks.N.conv_0.bias -> norm_1) has a gradient that is exactly 0 in
+    exact arithmetic and pure rounding noise in any finite precision: a relative error is meaningless there, so those six
+    tensors are named (STRUCTURAL_ZERO) and judged against the typical gradient magnitude instead -- every other parameter
+    gets the plain relative error, no floor."""
     rms = {k: float(v.grad.double().pow(2).mean().sqrt()) for k, v in ref64.items()}
     typical = sorted(rms.values())[len(rms) // 2]
     out = {}
     for k, v in ref64.items():
         b = v.grad.double().flatten()
         a = named_hip[k].grad.detach().cpu().double().flatten()
-        floor = floor_frac * typical * b.numel() ** 0.5
-        out[k] = float((a - b).norm() / (b.norm() + floor))
+        if STRUCTURAL_ZERO.match(k):
+            assert float(b.norm()) <= 1e-6 * typical * b.numel() ** 0.5, (k, float(b.norm()))      # the oracle agrees it is zero
+            out[k] = float(a.norm() / (typical * b.numel() ** 0.5))                                   # noise relative to a typical gradient
+        else:
+            out[k] = float((a - b).norm() / (b.norm() + 1e-300))
     return out
 
 
@@ -180,7 +189,7 @@ def count_flips(masks, trace64):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("precision,tol,gtol,max_flips", [("fp32", 1e-5, 1e-4, 24), ("bf16", 3e-2, 0.12, None)])
+@pytest.mark.parametrize("precision,tol,gtol,max_flips", [("fp32", 1e-5, 1e-5, 24), ("bf16", 3e-2, 0.10, 30000)])   # measured: fp32 grads 3.4e-6; bf16 grads 5.0e-2, 15 228 flips
 def test_generator_forward_backward(hip_device, tmp_path, precision, tol, gtol, max_flips):
     opt, model, spec, pg, pd, pv = build(precision, tmp_path)
     prev, state, real = make_inputs(2, 84, 84, 17)
@@ -299,13 +308,16 @@ def test_edge_shapes_generator_and_discriminator_features(hip_device, tmp_path, 
             assert rel_l2(f.cpu(), r_) < 1e-5
 
 
-@pytest.mark.parametrize("precision,ltol,gtol,dgtol", [("fp32", 1e-4, 1e-4, 1e-4), ("bf16", 5e-3, 0.12, 3e-2)])
-def test_train_step_losses_and_grads(hip_device, tmp_path, precision, ltol, gtol, dgtol):
+@pytest.mark.parametrize("precision,ltol,gtol,dgtol,env", [("fp32", 1e-4, 1e-5, 1e-5, "cheetah"), ("bf16", 5e-3, 0.10, 2.2e-2, "cheetah"),
+                                                           ("fp32", 1e-4, 1e-5, 1e-5, "walker")])   # measured: fp32 4.1e-6 / 3.4e-6, bf16 5.3e-2 / 1.07e-2
+def test_train_step_losses_and_grads(hip_device, tmp_path, precision, ltol, gtol, dgtol, env):
     """One G step and one D step (hinge GAN + feature matching + VGG + L1): every loss value and every parameter gradient
-    against the float64 oracle run with the branches (ReLU / LeakyReLU / max-pool / |.| / hinge) the HIP step took."""
-    opt, model, spec, pg, pd, pv = build(precision, tmp_path)
+    against the float64 oracle run with the branches (ReLU / LeakyReLU / max-pool / |.| / hinge) the HIP step took.
+    walker (BASELINE.json configs[3]): the 24-dimensional state changes the positional encoding and fc0 only."""
+    opt, model, spec, pg, pd, pv = build(precision, tmp_path, env=env)
     spec.lambda_feat, spec.lambda_vgg, spec.lambda_l1 = opt.lambda_feat, opt.lambda_vgg, opt.lambda_l1
-    prev, state, real = make_inputs(2, 84, 84, 17, seed=3)
+    prev, state, real = make_inputs(2, 84, 84, spec.state_dim, seed=3)
+    assert spec.state_dim == (24 if env == "walker" else 17)
     N = 2
     data = dict(prev_image=prev, state=state, image=real)
     d64 = lambda p: {k: v.double() for k, v in p.items()}  # noqa: E731
@@ -364,7 +376,7 @@ def test_loss_weights_reach_the_gradients(hip_device, tmp_path):
     pg64 = to64(pg)
     L64, _ = O.generator_losses(pg64, d64(pd), d64(pv), prev.double(), state.double(), real.double(), spec, masks=masks)
     sum(wts[k] * v for k, v in L64.items()).backward()
-    check_grads(grad_errors(dict(model.netG.named_parameters()), pg64), 1e-4, "weighted G losses")
+    check_grads(grad_errors(dict(model.netG.named_parameters()), pg64), 1e-5, "weighted G losses")
     # D step with unequal weights on the two hinge terms
     model.netD.store.zero_grad()
     d_losses = model(data, mode="discriminator")
@@ -376,7 +388,7 @@ def test_loss_weights_reach_the_gradients(hip_device, tmp_path):
     pd64 = to64(pd)
     D64 = O.discriminator_losses(None, pd64, prev.double(), state.double(), real.double(), spec, masks=dmasks, fake=fake_hip)
     (3.0 * D64["D_Fake"] + 0.25 * D64["D_real"]).backward()
-    check_grads(grad_errors(dict(model.netD.named_parameters()), pd64), 1e-4, "weighted D losses")
+    check_grads(grad_errors(dict(model.netD.named_parameters()), pd64), 1e-5, "weighted D losses")
 
 
 def test_dstep_reuses_the_gstep_real_pass(hip_device, tmp_path):
@@ -542,6 +554,17 @@ def test_rollout_matches_oracle_and_golden(hip_device, tmp_path):
     assert rel(frames[:, -1], torch.from_numpy(G["rollout_last"])) < 1e-4
     ref = O.rollout(pg, prev, states, spec)
     assert rel(frames, ref) < 1e-4
+    # several samples at once (frames of different samples used to overwrite each other: the layout kernel was handed a strided
+    # view of a batch-major buffer): every sample of a batch-3 rollout equals its own single-sample rollout
+    g = torch.Generator().manual_seed(77)
+    prev3 = torch.rand(3, 3, 84, 84, generator=g) * 2 - 1
+    states3 = torch.randn(3, 3, 17, generator=g)
+    f3 = rollout(model.netG, prev3, states3).cpu()
+    assert f3.shape == (3, 3, 3, 84, 84)
+    ref3 = O.rollout(pg, prev3, states3, spec)
+    assert rel(f3, ref3) < 1e-4
+    for i in range(3):
+        assert rel(f3[i:i + 1], rollout(model.netG, prev3[i:i + 1], states3[i:i + 1]).cpu()) < 1e-5
 
 
 def test_generator_256x256_bf16_runs_and_matches(hip_device, tmp_path):
@@ -558,7 +581,9 @@ def test_generator_256x256_bf16_runs_and_matches(hip_device, tmp_path):
         y = model.netG(prev.cuda(), state.cuda()).cpu()
         y_ref = O.generator_forward(pg, prev, state, spec)
     assert y.shape == (2, 3, 256, 256)
-    assert rel(y, y_ref) < 6e-2
+    e_l2, e_max = rel_l2(y, y_ref), rel(y, y_ref)
+    print("256x256 bf16 forward: rel-L2 %.2e, max-norm %.2e" % (e_l2, e_max))
+    assert e_l2 < 3e-2 and e_max < 6e-2                     # judged in rel-L2 like the 84x84 forward (measured there 1.5e-2)
 
 
 def test_full_size_shard_additivity_bf16(hip_device, tmp_path):
@@ -591,7 +616,101 @@ def test_full_size_shard_additivity_bf16(hip_device, tmp_path):
         print(f"shard additivity {name}: {err:.3e}")
         # bf16 operands; the IN split geometry depends on the batch, so a LeakyReLU input may round to the other side of 0
         # and flip a 4x4 footprint of the D gradient (measured: G 1e-2, D 4e-2)
-        assert err < (2e-2 if name == "G" else 8e-2), (name, err)
+        assert err < (2.5e-2 if name == "G" else 8e-2), (name, err)          # measured 1.2e-2 (G), 4.0e-2 (D): twice that
+
+
+def test_walker_trainer_step_full_batch_bf16(hip_device, tmp_path):
+    """BASELINE.json configs[3] on one GPU: the walker train step at bs 64, bf16 -- finite losses, and two identical steps
+    from the same weights give bitwise identical gradients (every overlap on)."""
+    from s2p_amd.trainers.pix2pix_trainer import Pix2PixTrainer
+    opt = TrainOptions().parse(["--env_type", "walker", "--batchSize", "64", "--precision", "bf16", "--gpu_ids", "0",
+                                "--checkpoints_dir", str(tmp_path)], quiet=True)
+    tr = Pix2PixTrainer(opt)
+    m = tr.pix2pix_model
+    assert opt.state_dim == 24
+    prev, state, real = make_inputs(64, 84, 84, 24, seed=41)
+    data = dict(prev_image=prev.cuda(), state=state.cuda(), image=real.cuda())
+
+    def grads():
+        tr.optimizer_G.zero_grad()
+        Lg, _ = m(data, mode="generator"); tr._backward(Lg)
+        gG = m.netG.store.grad.clone()
+        tr.optimizer_D.zero_grad()
+        Ld = m(data, mode="discriminator"); tr._backward(Ld)
+        torch.cuda.synchronize()
+        return gG, m.netD.store.grad.clone(), {k: float(v) for k, v in {**Lg, **Ld}.items()}
+
+    a, b = grads(), grads()
+    assert all(v == v and abs(v) < 1e4 for v in a[2].values()), a[2]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert float(a[0].abs().max()) > 0 and float(a[1].abs().max()) > 0
+    tr.run_generator_one_step(data); tr.run_discriminator_one_step(data)
+    torch.cuda.synchronize()
+    assert all(v == v for v in (float(x) for x in tr.get_latest_losses().values()))
+
+
+def _rollout_models(tmp_path, size):
+    from s2p_amd.options.test_options import TestOptions
+    spec = O.Spec()
+    pg = randomize(O.init_params(O.generator_param_shapes(spec), 1), 11, 1.0)
+    out = {}
+    for prec in ("fp32", "bf16"):
+        opt = TestOptions().parse(["--env_type", "cheetah", "--gpu_ids", "0", "--random_init", "--precision", prec,
+                                   "--checkpoints_dir", str(tmp_path), "--crop_size", str(size)], quiet=True)
+        model = Pix2PixModel(opt)
+        model.netG.load_state_dict(pg)
+        out[prec] = model
+    return spec, pg, out
+
+
+def test_rollout_256_fp32_matches_float64_oracle(hip_device, tmp_path):
+    """BASELINE.json configs[4] geometry (256x256 frames): 1 sample x 4 autoregressive steps, HIP fp32 against the float64
+    oracle at 1e-4 -- the frames stay on the device in NHWC between steps."""
+    from s2p_amd.rollout import rollout
+    spec, pg, models = _rollout_models(tmp_path, 256)
+    g = torch.Generator().manual_seed(21)
+    prev = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
+    states = torch.randn(1, 4, 17, generator=g)
+    frames = rollout(models["fp32"].netG, prev, states).cpu()
+    ref = O.rollout({k: v.double() for k, v in pg.items()}, prev.double(), states.double(), spec)
+    for t_ in range(4):
+        e = rel_l2(frames[:, t_], ref[:, t_])
+        print("256x256 rollout step %d: fp32 vs float64 rel-L2 %.2e" % (t_ + 1, e))
+        assert e < 1e-4, (t_, e)
+
+
+def test_rollout_256_seq32_bf16_drift_against_fp32(hip_device, tmp_path):
+    """BASELINE.json configs[4] as written, on one GPU: bs 16 x 256x256 x seq_len 32, bf16, against the SAME rollout in HIP fp32
+    (itself pinned to the float64 oracle by the test above).  The autoregressive loop feeds every frame back.  With RANDOM
+    weights the map I -> G(I, s) is expansive: ANY perturbation grows ~3.2x per step (the fp32-vs-float64 error of the test
+    above grows 2.7e-6 -> 9.0e-6 -> 2.9e-5 -> 9.2e-5), so after ~6 steps two rollouts that differ by a rounding are
+    uncorrelated (PSNR of two independent frames of this generator: 11.5 dB) -- a property of the untrained dynamics, not of
+    the bf16 path.  What is pinned here: the one-step bf16 error (PSNR / SSIM via s2p_image_metrics, data range 2), that the
+    drift grows no faster per step than that amplification (no precision-specific blow-up), bounded finite frames over all
+    32 steps, and bitwise reproducibility of the bf16 rollout."""
+    from s2p_amd import metrics
+    from s2p_amd.rollout import rollout
+    spec, pg, models = _rollout_models(tmp_path, 256)
+    B, T = 16, 32
+    g = torch.Generator().manual_seed(22)
+    prev = torch.rand(B, 3, 256, 256, generator=g) * 2 - 1
+    states = torch.randn(B, T, 17, generator=g)
+    f32 = rollout(models["fp32"].netG, prev, states)
+    bf = rollout(models["bf16"].netG, prev, states)
+    bf2 = rollout(models["bf16"].netG, prev, states)
+    torch.cuda.synchronize()
+    assert f32.shape == bf.shape == (B, T, 3, 256, 256)
+    assert torch.equal(bf, bf2)
+    assert bool(torch.isfinite(bf).all()) and float(bf.abs().max()) <= 1.0
+    worst = []
+    for t_ in range(T):
+        p, s_ = metrics.image_metrics(bf[:, t_], f32[:, t_])
+        worst.append((float(p.min()), float(s_.min())))
+    print("bf16 vs fp32 rollout, worst sample per step (PSNR dB, SSIM): " + " ".join("%d:%.1f/%.3f" % (i + 1, a, b) for i, (a, b) in enumerate(worst)))
+    assert worst[0][0] > 45.0 and worst[0][1] > 0.995, worst[0]         # one step: bf16 rounding only (measured 48.2 dB / 0.999)
+    for t_ in range(1, 5):                                              # growth per step <= 12.5 dB = 4.2x (measured 10.3, 9.5, 8.2, 5.5 dB)
+        assert worst[t_][0] > worst[t_ - 1][0] - 12.5, (t_, worst[t_ - 1], worst[t_])
+    assert min(w[0] for w in worst) > 11.0, min(w[0] for w in worst)     # never worse than two unrelated frames: no blow-up, no NaN
 
 
 def test_simple_test_cli_seq_len_5(hip_device, tmp_path):

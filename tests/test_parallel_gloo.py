@@ -37,6 +37,30 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def test_flat_grad_allreduce_and_broadcast_world8():
+    """The world size the driver's scaling run ends at: SUM over 8 contributors, broadcast from rank 0 to 7 others, max over 8,
+    and the 1/8 that Adam's grad_scale applies to the sum."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    W = 8
+    procs = [ctx.Process(target=_worker, args=(r, W, port, q)) for r in range(W)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(W)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    total = sum(r[3] for r in res)
+    for (rank, m, g, l, t, rp, ws) in res:
+        assert ws == W and rp == 1 and t == float(W)            # max over ranks of (1 + rank)
+        assert torch.equal(m, _FakeStore(0).master)             # everyone holds rank 0's parameters
+        assert torch.equal(g, res[0][2])                        # identical reduced buffer on every rank
+        assert torch.allclose(g, total, rtol=1e-6, atol=1e-6)
+    mean = res[0][2] * (1.0 / W)                                # what the fused Adam sees (grad_scale = 1 / world)
+    assert torch.allclose(mean, total / W, rtol=1e-6, atol=1e-6)
+
+
 def test_flat_grad_allreduce_and_broadcast_world2():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
