@@ -598,6 +598,227 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// PAIR form for launches with several tiles per CU (the grouped gamma/beta conv: 24 tiles per CU; VGG conv3 at N 128: 2): one
+// workgroup computes TWO neighbouring 64-channel slabs of the same image from ONE resident plane.  Wave set s (waves 4s..4s+3)
+// owns slab 2*pair + s and runs EVERY K step on it with its own 6-stage weight ring; both sets read the same plane buffers.
+// Against two single-slab workgroups this halves the plane traffic and the prologues, and there is no K split, hence no
+// accumulator exchange; the LDS fragment traffic per MFMA is unchanged (11 reads per 28 MFMAs per wave and step).
+template <int PB, int WP, int DIAG>
+__global__ __launch_bounds__(512) void conv_plane_pair_kernel(const PlaneArgs a) {
+  typedef __bf16 T;
+  constexpr int BPIX = 4 * PB * 16;
+  constexpr int RINGB = PL_RING * PL_WST;                      // one set's weight ring
+  constexpr int MAIN = 2 * PL_PBUF + 2 * RINGB;
+  constexpr int EPI = BPIX * PL_ERS;                           // one set's staging rows
+  constexpr int SMEM = 2 * EPI > MAIN ? 2 * EPI : MAIN;
+  __shared__ __attribute__((aligned(1024))) char smem[SMEM];
+  char* const pbase = smem;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int set = wave >> 2, wq = wave & 3;
+  const int q = lane >> 4, l15 = lane & 15;
+  const int g = blockIdx.y;
+  int img, cpair;
+  {
+    const int bid = blockIdx.x, np = a.nco >> 1;
+    if ((a.N & 7) == 0) { const int xcd = bid & 7, k = bid >> 3; cpair = k % np; img = (k / np) * 8 + xcd; }
+    else { cpair = bid % np; img = bid / np; }
+  }
+  const int co_base = (2 * cpair + set) * 64;                   // this wave set's slab
+  const int HW = a.H * a.W;
+  char* const wbase = smem + 2 * PL_PBUF + set * RINGB;         // this wave set's ring
+  const T* xg = (const T*)a.x + (size_t)g * a.x_gstride;
+  const T* wg = (const T*)a.w + (size_t)g * a.w_gstride;
+  const i32x4 xrs = s2p_make_rsrc(xg, a.x_bytes - (unsigned)g * (unsigned)a.x_gstride * 2u);
+  const i32x4 wrs = s2p_make_rsrc(wg, a.w_bytes);
+  const unsigned p_lds = __builtin_amdgcn_readfirstlane(s2p_lds_addr(pbase));
+  const unsigned w_lds = __builtin_amdgcn_readfirstlane(s2p_lds_addr(wbase));
+  const unsigned OOB = 0x80000000u;
+  // plane: 32 pieces per half-slab, wave w issues pieces w, w + 8, w + 16, w + 24 (one per K step 0..3 / 9..12)
+  int hv[4]; unsigned hdst[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int ii = wave + 8 * k;
+    const int cp = ii & 1, pg = ii >> 1;
+    const int pos = 32 * pg + (lane >> 1);
+    const int pm = pos - 1;
+    const int yy = pm / WP - 1, xx = pm % WP;
+    const bool ok = pos >= 1 && yy >= 0 && yy < a.H && xx < a.W;
+    hv[k] = ok ? (int)((((unsigned)(img * a.H + yy) * a.W + xx) * a.x_pitch) * 2u + (2 * cp + (lane & 1)) * 16) : (int)OOB;
+    hdst[k] = (unsigned)(cp * PL_CPS + pg * 1024);
+  }
+  // weights: 4 pieces per stage and set; wave w issues piece (w & 3) of ITS set's stage
+  int wv; unsigned wdst;
+  {
+    const int cp = wave & 1, cohalf = (wave >> 1) & 1;
+    const int co = co_base + 32 * cohalf + (lane >> 1);
+    wv = co < a.Cout ? (int)((unsigned)co * a.w_row * 2u + (2 * cp + (lane & 1)) * 16) : (int)OOB;
+    wdst = (unsigned)(cp * 2048 + cohalf * 1024);
+  }
+  int wto[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wto[t] = a.wt[t] * a.Cin * 2;
+  const int nhs = a.Cin / 32;
+  auto issue_plane1 = [&](int buf, int hs, int k) {
+    pl_dma16(xrs, p_lds + (unsigned)(buf * PL_PBUF) + hdst[k], hs < nhs ? hv[k] : (int)OOB, hs * 64);
+  };
+  auto issue_w = [&](int stage, int tap_off, int hs) {
+    pl_dma16(wrs, w_lds + (unsigned)(stage * PL_WST) + wdst, hs < nhs ? wv : (int)OOB, tap_off + hs * 64);
+  };
+  // prologue: the plane of half-slab 0, the weight stages of K steps 0, 1, 2
+#pragma unroll
+  for (int k = 0; k < 4; ++k) issue_plane1(0, 0, k);
+  issue_w(0, wto[0], 0);
+  issue_w(1, wto[1], 0);
+  issue_w(2, wto[2], 0);
+  int bB[PB];
+  {
+    const float rw = 1.0f / (float)a.W;
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      int m = (wq * PB + j) * 16 + l15;
+      if (m >= HW) m = HW - 1;
+      const int y = (int)(((float)m + 0.5f) * rw), x = m - y * a.W;
+      bB[j] = (q >> 1) * PL_CPS + (q & 1) * 16 + (y * WP + x) * 32;
+    }
+  }
+  const int bA = (q >> 1) * 2048 + l15 * 32 + (q & 1) * 16;
+  f32x4v acc[4][PB];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < PB; ++j) acc[i][j] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+  auto read_a = [&](auto uc, auto ic, bf16x8 (&fa)[4]) {
+    constexpr int u = decltype(uc)::value % 18, i = decltype(ic)::value;
+    fa[i] = *(const bf16x8*)(wbase + (u % PL_RING) * PL_WST + i * 512 + bA);
+  };
+  auto read_b = [&](auto uc, auto jc, bf16x8 (&fb)[PB]) {
+    constexpr int u = decltype(uc)::value % 18, j = decltype(jc)::value;
+    constexpr int t = u % 9, hsl = u / 9;
+    fb[j] = *(const bf16x8*)(pbase + hsl * PL_PBUF + ((t / 3) * WP + (t % 3)) * 32 + bB[j]);
+  };
+  auto mfma4 = [&](auto jc, bf16x8 (&fa)[4], bf16x8 (&fb)[PB]) {
+    constexpr int j = decltype(jc)::value;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+  };
+  typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1;
+  typedef std::integral_constant<int, 2> I2; typedef std::integral_constant<int, 3> I3;
+  typedef std::integral_constant<int, 4> I4; typedef std::integral_constant<int, 5> I5;
+  typedef std::integral_constant<int, 6> I6;
+  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");              // plane 0 and the stage of step 0 have landed ...
+  __builtin_amdgcn_s_barrier();                                 // ... for every wave
+  __builtin_amdgcn_sched_barrier(0);
+  bf16x8 fa[4], fb[PB];
+  pl_static_for<0, 4>([&](auto ic) { read_a(I0{}, ic, fa); });
+  pl_static_for<0, PB>([&](auto jc) { read_b(I0{}, jc, fb); });
+  // K step u of an 18-step iteration (two half-slabs): MFMAs of step u on the fragments in registers; between them the
+  // fragment reads of step u + 1, the weight piece of step u + 3 (ring stage (u + 3) % 6, last read in step u - 4) and, in
+  // steps 0..3 / 9..12, one piece of the plane of the next-but-one / next half-slab (buffer 1 is free from step 17 of the
+  // previous iteration and needed by the reads of step 8; buffer 0 is free from step 8 and needed in step 17).
+  for (int k2 = 0; k2 < nhs; k2 += 2) {
+    pl_static_for<0, 18>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      typedef std::integral_constant<int, u + 1> un;
+      constexpr int up = (u + 17) % 18;                         // previous step: what it issued may still be in flight
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (up <= 3 || (up >= 9 && up <= 12)) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 na[4], nb[PB];
+      read_a(un{}, I0{}, na); read_a(un{}, I1{}, na);
+      mfma4(I0{}, fa, fb);
+      __builtin_amdgcn_sched_barrier(0);
+      read_a(un{}, I2{}, na); read_a(un{}, I3{}, na);
+      mfma4(I1{}, fa, fb);
+      __builtin_amdgcn_sched_barrier(0);
+      read_b(un{}, I0{}, nb); read_b(un{}, I1{}, nb);
+      { constexpr int u3 = u + 3; issue_w(u3 % PL_RING, wto[u3 % 9], k2 + u3 / 9); }
+      mfma4(I2{}, fa, fb);
+      __builtin_amdgcn_sched_barrier(0);
+      read_b(un{}, I2{}, nb); read_b(un{}, I3{}, nb);
+      if constexpr (u <= 3) issue_plane1(1, k2 + 1, u);
+      if constexpr (u >= 9 && u <= 12) issue_plane1(0, k2 + 2, u - 9);
+      mfma4(I3{}, fa, fb);
+      __builtin_amdgcn_sched_barrier(0);
+      read_b(un{}, I4{}, nb); read_b(un{}, I5{}, nb);
+      mfma4(I4{}, fa, fb);
+      __builtin_amdgcn_sched_barrier(0);
+      read_b(un{}, I6{}, nb);
+      mfma4(I5{}, fa, fb);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma4(I6{}, fa, fb);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = na[i];
+#pragma unroll
+      for (int j = 0; j < PB; ++j) fb[j] = nb[j];
+    });
+  }
+  S2P_WAIT_VMCNT(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  // ---- epilogue: every wave stages its 28 tiles into its set's [pixel][co] rows; then 16-B stores of both slabs --------
+  {
+    char* stg = smem + set * EPI;
+    const float* bias = a.bias ? a.bias + (size_t)g * a.Cout + co_base : nullptr;
+    float bv[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[i][e] = bias ? bias[16 * i + 4 * q + e] : 0.f;
+    auto stage_out = [&](auto f) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+          const int px = (wq * PB + j) * 16 + l15;
+          const f32x4v v = acc[i][j];
+          bf16x4 o = {(__bf16)f(v[0] + bv[i][0]), (__bf16)f(v[1] + bv[i][1]), (__bf16)f(v[2] + bv[i][2]), (__bf16)f(v[3] + bv[i][3])};
+          *(bf16x4*)(stg + px * PL_ERS + (16 * i + 4 * q) * 2) = o;
+        }
+    };
+    if (a.act == S2P_ACT_TANH) stage_out([](float v) { return tanhf(v); });
+    else if (a.act == S2P_ACT_SWISH) stage_out([](float v) { return v / (1.f + expf(-v)); });
+    else {
+      const float ns = a.act == S2P_ACT_RELU ? 0.f : (a.act == S2P_ACT_LRELU ? a.slope : 1.f);
+      stage_out([ns](float v) { return v > 0.f ? v : v * ns; });
+    }
+  }
+  __syncthreads();
+  {
+    T* yg = (T*)a.y + (size_t)g * a.y_gstride;
+    const T* auxg = a.aux ? (const T*)a.aux + (size_t)g * a.y_gstride : nullptr;
+    const T* aux2g = a.aux2 ? (const T*)a.aux2 + (size_t)g * a.y_gstride : nullptr;
+    const bool epi_add = a.epi == S2P_EPI_ADD;
+    const bool g_tanh = a.gact == S2P_ACT_TANH;
+    const float gneg = a.gact == S2P_ACT_RELU ? 0.f : (a.gact == S2P_ACT_LRELU ? a.gslope : 1.f);
+    for (int idx = tid; idx < HW * 16; idx += 512) {            // (row, 16 chunks of 8 channels: the two slabs side by side)
+      const int row = idx >> 4, ch16 = idx & 15, sl = ch16 >> 3, ch = ch16 & 7;
+      Chunk<T> c;
+      c.raw = *(const u32x4*)(smem + sl * EPI + row * PL_ERS + ch * 16);
+      const size_t go = ((size_t)img * HW + row) * a.y_pitch + (2 * cpair + sl) * 64 + ch * 8;
+      if (a.epi != S2P_EPI_STORE) {
+        Chunk<T> x, x2;
+        x.raw = *(const u32x4*)(auxg + go);
+        x2.raw = (u32x4){0u, 0u, 0u, 0u};
+        if (aux2g) x2.raw = *(const u32x4*)(aux2g + go);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float v = c.get(e), xv = x.get(e);
+          const float f = g_tanh ? 1.f - xv * xv : (xv > 0.f ? 1.f : gneg);
+          v = epi_add ? v + xv : (v + x2.get(e)) * f;
+          c.set(e, v);
+        }
+      }
+      *(u32x4*)(yg + go) = c.raw;
+    }
+  }
+}
+
 bool s2p_conv_plane_applicable(const PlaneArgs& a) {
   if (a.H > 21 || a.W > 21 || a.H < 3 || a.W < 3) return false;      // (H+2)*22 + 2 <= 512 positions
   const int HW = a.H * a.W;
@@ -616,6 +837,13 @@ int s2p_conv_plane_launch(PlaneArgs& a, int groups, hipStream_t st) {
   PL_DIAG_CASE(1) PL_DIAG_CASE(2) PL_DIAG_CASE(4) PL_DIAG_CASE(5) PL_DIAG_CASE(8) PL_DIAG_CASE(16) PL_DIAG_CASE(17) PL_DIAG_CASE(20) PL_DIAG_CASE(21) PL_DIAG_CASE(64) PL_DIAG_CASE(128)
 #undef PL_DIAG_CASE
 #endif
+  // several tiles per CU and an even slab count: two slabs per workgroup from one resident plane (no accumulator exchange)
+  if (!a.y2 && (a.nco & 1) == 0 && (long long)a.N * a.nco * groups > 256 && !s2p_env_set("S2P_NO_PLANE_PAIR")) {
+    dim3 gp(a.N * (a.nco / 2), groups);
+    hipLaunchKernelGGL((conv_plane_pair_kernel<7, 22, 0>), gp, dim3(512), 0, st, a);
+    S2P_CHECK_LAUNCH("conv_plane_pair_kernel");
+    return 0;
+  }
   if (a.y2 && a.xn) { hipLaunchKernelGGL((conv_plane_kernel<7, 22, 0, 2>), grid, dim3(512), 0, st, a); S2P_CHECK_LAUNCH("conv_plane_kernel(mat bwd)"); return 0; }
   if (a.y2) { hipLaunchKernelGGL((conv_plane_kernel<7, 22, 0, 1>), grid, dim3(512), 0, st, a); S2P_CHECK_LAUNCH("conv_plane_kernel(mat)"); return 0; }
   hipLaunchKernelGGL((conv_plane_kernel<7, 22, 0>), grid, dim3(512), 0, st, a);

@@ -72,6 +72,8 @@ CONV_CASES = [
     (256, 128, 3, 1, 1, False, False, 19, 21, 8),  # plane-resident kernel (bf16): 8 half-slabs, XCD-aware (image, slab) order, H != W
     (64, 64, 3, 1, 1, False, False, 20, 17, 9),    # plane-resident kernel: one co slab, 340-px plane (last blocks padded), N % 8 != 0
     (192, 64, 3, 1, 1, False, False, 21, 21, 2),   # plane-resident kernel: odd number of 64-channel input slabs
+    (128, 256, 3, 1, 1, False, False, 21, 20, 16), # plane-resident PAIR kernel (> 256 tiles, even slab count): two slabs per workgroup
+    (64, 128, 3, 1, 1, False, False, 19, 21, 131), # ... one pair per image, N % 8 != 0
 ]
 
 
