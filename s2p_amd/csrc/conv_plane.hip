@@ -317,8 +317,9 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
     };
     if (a.act == S2P_ACT_TANH) stage_out([](float v) { return tanhf(v); });
     else if (a.act == S2P_ACT_SWISH) stage_out([](float v) { return v / (1.f + expf(-v)); });
+    else if (a.act == S2P_ACT_NONE) stage_out([](float v) { return v; });        // (dgrads, gamma/beta conv: the pass is VALU-bound)
     else {
-      const float ns = a.act == S2P_ACT_RELU ? 0.f : (a.act == S2P_ACT_LRELU ? a.slope : 1.f);   // relu / lrelu / none
+      const float ns = a.act == S2P_ACT_RELU ? 0.f : a.slope;                    // relu / lrelu
       stage_out([ns](float v) { return v > 0.f ? v : v * ns; });
     }
   };
@@ -783,8 +784,9 @@ __global__ __launch_bounds__(512) void conv_plane_pair_kernel(const PlaneArgs a)
     };
     if (a.act == S2P_ACT_TANH) stage_out([](float v) { return tanhf(v); });
     else if (a.act == S2P_ACT_SWISH) stage_out([](float v) { return v / (1.f + expf(-v)); });
+    else if (a.act == S2P_ACT_NONE) stage_out([](float v) { return v; });        // (dgrads, gamma/beta conv: the pass is VALU-bound)
     else {
-      const float ns = a.act == S2P_ACT_RELU ? 0.f : (a.act == S2P_ACT_LRELU ? a.slope : 1.f);
+      const float ns = a.act == S2P_ACT_RELU ? 0.f : a.slope;
       stage_out([ns](float v) { return v > 0.f ? v : v * ns; });
     }
   }
