@@ -80,7 +80,9 @@ def spade_resblk_aggregate(recs, N, HW):
                 mfma_only_frac=round(flops / (t_mfma * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
                 norm_hbm_tbps=round(nbytes / (t_norm * 1e-3) / 1e12, 2) if t_norm > 0 else None,
                 includes="6 blocks: 12 conv3x3 256->256 (fwd, dgrad, wgrad), grouped gamma/beta conv 12x(128->512) (fwd, dgrad, wgrad), "
-                         "shared conv 3->1536 (fwd, wgrad), 24 IN-stats + 24 MAT-apply halves, 12 MAT backward pairs; the fp32 state affine is excluded")
+                         "shared conv 3->1536 (fwd, wgrad), the 12 MAT norms forward and backward -- 11 forward and all 12 backward norms run "
+                         "inside conv launches (s2p_conv2d_fwd_mat / s2p_conv2d_dgrad_mat: their HBM-bound tails are in mfma_ms), norm_ms is "
+                         "what is left as separate launches; the fp32 state affine is excluded")
 
 
 def cpu_baseline(args, state_dim):
@@ -362,8 +364,8 @@ def main():
             print("[bench] traffic: %s" % e, file=sys.stderr)
         roofline = dict(bound="mfma", measured="three instrumented eager steps with every launch on ONE stream (HIP events around each "
                                                "launch, median of the three samples per launch): kernel-alone durations; rocprofv3 counterpart: bench.py --serial-streams",
-                        kernel="implicit-GEMM conv family: conv_halo/conv_dma/conv_gather (fwd, dgrad) + wgrad_dma/wgrad "
-                                             "+ thin_tiled kernels, all %d launches of one step" % len(recs),
+                        kernel="conv family: conv_plane / conv_halo / conv_dma / conv_gather (fwd, dgrad, incl. fused norm tails) + wgrad_slab / "
+                                             "wgrad_dma / wgrad + thin kernels, all %d launches of one step" % len(recs),
                         dominant_layer=dominant, spade_resblk_fwd_bwd=resblk,
                         achieved=round(ach, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                         traffic=traffic, traffic_detail=traffic_detail, algorithmic_gflop_per_step=round(tot_f / 1e9, 1), conv_ms_per_step=round(tot_ms, 3),

@@ -33,7 +33,8 @@ def _worker(rank, world, port, q):
     dp.all_reduce_grads(st)
     t = dp.max_over_ranks(1.0 + rank)
     dp.barrier()
-    q.put((rank, st.master.clone(), st.grad.clone(), g_local, t, st.repacked, dp.world_size))
+    # numpy copies: a torch tensor in a multiprocessing queue is rebuilt through the SENDER's socket, which is gone once it exits
+    q.put((rank, st.master.numpy().copy(), st.grad.numpy().copy(), g_local.numpy().copy(), t, st.repacked, dp.world_size))
     dist.destroy_process_group()
 
 
@@ -48,6 +49,7 @@ def test_flat_grad_allreduce_and_broadcast_world8():
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=180) for _ in range(W)], key=lambda r: r[0])
+    res = [(r[0], torch.from_numpy(r[1]), torch.from_numpy(r[2]), torch.from_numpy(r[3]), r[4], r[5], r[6]) for r in res]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -69,6 +71,7 @@ def test_flat_grad_allreduce_and_broadcast_world2():
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda r: r[0])
+    res = [(r[0], torch.from_numpy(r[1]), torch.from_numpy(r[2]), torch.from_numpy(r[3]), r[4], r[5], r[6]) for r in res]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
