@@ -503,28 +503,6 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
     __syncthreads();
     const float gneg = a.n_act == S2P_ACT_RELU ? 0.f : (a.n_act == S2P_ACT_LRELU ? a.n_slope : 1.f);
     unsigned long long posmask = 0ull;                          // activation branch per (row k, element e): pass 2 reuses pass 1's
-    T* dgo = a.dgb ? (T*)a.dgb + (size_t)img * HW * a.dgb_pitch + lc : nullptr;
-    // ---- pass 0: d(gamma_img | beta_img) = dy * xhat | dy do not depend on the plane sums: they are stored first, so that
-    //      their HBM writes run under the reductions below
-    if (dgo) {
-#pragma unroll
-      for (int k = 0; k < MAXR; ++k) {
-        const int row = r0 + 64 * k;
-        if (row >= HW) break;
-        Chunk<T> o1, o2;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int cl = ch * 8 + e;
-          const float m = cst[cl], r = cst[64 + cl], gg = cst[128 + cl] + gv[k].get(e), bb = cst[192 + cl] + bv[k].get(e);
-          const float xh = (xv[k].get(e) - m) * r;
-          const float yv = __builtin_fmaf(xh, gg, bb);
-          const float dy = dv[k].get(e) * (yv > 0.f ? 1.f : gneg);
-          o1.set(e, dy * xh); o2.set(e, dy);
-        }
-        *(u32x4*)(dgo + (size_t)row * a.dgb_pitch) = o1.raw;
-        *(u32x4*)(dgo + (size_t)row * a.dgb_pitch + a.Cout) = o2.raw;
-      }
-    }
     // ---- pass 1: the four plane sums
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -564,12 +542,13 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
     __syncthreads();
     // ---- pass 2: outputs
     T* dxo = (T*)a.y2 + (size_t)img * HW * a.y2_pitch + lc;
+    T* dgo = a.dgb ? (T*)a.dgb + (size_t)img * HW * a.dgb_pitch + lc : nullptr;
     const T* rsb = a.res ? (const T*)a.res + (size_t)img * HW * a.res_pitch + lc : nullptr;
 #pragma unroll
     for (int k = 0; k < MAXR; ++k) {
       const int row = r0 + 64 * k;
       if (row >= HW) break;
-      Chunk<T> o0;
+      Chunk<T> o0, o1, o2;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int cl = ch * 8 + e;
@@ -578,6 +557,8 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
         const float dy = dv[k].get(e) * (((posmask >> (k * 8 + e)) & 1ull) ? 1.f : gneg);
         const float dxh = dy * gg;
         o0.set(e, r * (dxh - s1 - xh * s2));
+        o1.set(e, dy * xh);
+        o2.set(e, dy);
       }
       if (rsb) {                                                // skip-connection gradient folded into the store (fp32 add, one rounding)
         Chunk<T> rv; rv.raw = *(const u32x4*)(rsb + (size_t)row * a.res_pitch);
@@ -585,6 +566,10 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
         for (int e = 0; e < 8; ++e) o0.set(e, o0.get(e) + rv.get(e));
       }
       *(u32x4*)(dxo + (size_t)row * a.y2_pitch) = o0.raw;
+      if (dgo) {
+        *(u32x4*)(dgo + (size_t)row * a.dgb_pitch) = o1.raw;
+        *(u32x4*)(dgo + (size_t)row * a.dgb_pitch + a.Cout) = o2.raw;
+      }
     }
   }
   if constexpr ((DIAG & 128) != 0) {
