@@ -36,3 +36,14 @@ t_fused = timeit(lambda: ops.conv_fwd_mat(geom, x, wf, b, C, gb, 512, st, 512, A
 t_fused_res = timeit(lambda: ops.conv_fwd_mat(geom, x, wf, b, C, gb, 512, st, 512, ACT_LRELU, 0.2, aux=x, epi=EPI_ADD))
 print("conv %.1f us | conv+skip %.1f | norm %.1f | conv -> norm (two launches) %.1f | fused %.1f | fused + skip %.1f" % (
     t_conv, t_conv_res, t_norm, t_conv + t_norm, t_fused, t_fused_res))
+# backward: dgrad + norm backward, separate vs fused
+wb = (torch.randn(1, C, 9, C, device=dev) / math.sqrt(C * 9)).to(dt)
+dyv = torch.randn(N, 21, 21, C, device=dev).to(dt)
+ym, stats = ops.in_norm_fwd(x, C, gb, 512, st, 512, ACT_LRELU, 0.2)
+dgb = torch.empty_like(gb); dst = torch.empty_like(st)
+t_dg = timeit(lambda: ops.conv_dgrad(geom, dyv, wb, tuple(x.shape), C))
+dm = ops.conv_dgrad(geom, dyv, wb, tuple(x.shape), C)
+t_nb = timeit(lambda: ops.in_bwd(dm, x, C, stats, gb, 512, st, 512, ACT_LRELU, 0.2, dgb, 512, dst, 512))
+t_fb = timeit(lambda: ops.conv_dgrad_mat(geom, dyv, wb, x, C, stats, gb, 512, st, 512, ACT_LRELU, 0.2, dgb, 512, dst, 512))
+t_fbr = timeit(lambda: ops.conv_dgrad_mat(geom, dyv, wb, x, C, stats, gb, 512, st, 512, ACT_LRELU, 0.2, dgb, 512, dst, 512, res=x))
+print("dgrad %.1f us | norm bwd %.1f | two launches %.1f | fused %.1f | fused + skip gradient %.1f" % (t_dg, t_nb, t_dg + t_nb, t_fb, t_fbr))

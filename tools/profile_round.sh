@@ -43,7 +43,7 @@ for k, cs in acc.items():
     if "SQ_VALU_MFMA_BUSY_CYCLES" in cs and "GRBM_GUI_ACTIVE" in cs:
         e["mfma_util"] = (cs["SQ_VALU_MFMA_BUSY_CYCLES"][0] / cs["SQ_VALU_MFMA_BUSY_CYCLES"][1]) / (cs["GRBM_GUI_ACTIVE"][0] / cs["GRBM_GUI_ACTIVE"][1] / 8 * 1024)
     out[k] = e
-# provenance: the library version the counters were taken on (bench.py reports `traffic` only while it matches the loaded
+# provenance: the library version the counters were taken on (bench.py reports traffic only while it matches the loaded
 # library); the commit is added when the file is copied into profiles/ (the GPU box has no .git)
 import ctypes
 out["_meta"] = {"s2p_version": ctypes.CDLL(R + "/s2p_amd/csrc/libs2p_hip.so").s2p_version(), "commit": None, "tag": TAG}
