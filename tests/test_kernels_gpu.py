@@ -72,7 +72,7 @@ CONV_CASES = [
     (256, 128, 3, 1, 1, False, False, 19, 21, 8),  # plane-resident kernel (bf16): 8 half-slabs, XCD-aware (image, slab) order, H != W
     (64, 64, 3, 1, 1, False, False, 20, 17, 9),    # plane-resident kernel: one co slab, 340-px plane (last blocks padded), N % 8 != 0
     (192, 64, 3, 1, 1, False, False, 21, 21, 2),   # plane-resident kernel: odd number of 64-channel input slabs
-    (128, 256, 3, 1, 1, False, False, 21, 20, 16), # plane-resident PAIR kernel (> 256 tiles, even slab count): two slabs per workgroup
+    (128, 256, 3, 1, 1, False, False, 21, 20, 72), # plane-resident PAIR kernel (288 tiles > 256, even slab count): two slabs per workgroup
     (64, 128, 3, 1, 1, False, False, 19, 21, 131), # ... one pair per image, N % 8 != 0
 ]
 
@@ -719,3 +719,40 @@ def test_conv_dgrad_mat_fused(hip_device, dtype, shape, with_res):
     assert rel_err(nchw(dx1, C), ref_dx) < TOL[dtype]
     assert rel_err(nchw(dgb1, 2 * C + 16)[:, 16:16 + 2 * C], gbr.grad[:, 16:16 + 2 * C]) < TOL[dtype]
     assert rel_err(dst1.cpu()[:, 8:8 + 2 * C], str_.grad[:, 8:8 + 2 * C]) < (1e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("N,HW_", [(2, (21, 21)), (16, (21, 21)), (5, (18, 20)), (130, (16, 21))])      # the last: 260 / 780 tiles -> PAIR kernel
+def test_conv_plane_kernels_epilogues_and_groups(hip_device, N, HW_):
+    """Every epilogue form of the plane-resident kernels (conv_plane.hip) on shapes that take them -- N * Cout / 64 <= 256 tiles:
+    the K-split kernel; more: the PAIR kernel -- against float64: bias + ReLU, residual add, the dgrad with the fused
+    producer-activation gradient and a second incoming gradient (the VGG taps), and a grouped conv with bias (the gamma/beta heads)."""
+    dev = hip_device
+    dtype = torch.bfloat16
+    H, W = HW_
+    C = 128
+    g = torch.Generator().manual_seed(3)
+    r = lambda *sh: torch.randn(*sh, generator=g).bfloat16().float()      # noqa: E731
+    x, w, b = r(N, C, H, W), r(C, C, 3, 3) / math.sqrt(C * 9), torch.randn(C, generator=g)
+    geom = ops.ConvGeom(C, C, 3, 1, 1)
+    xd, wf, wb = nhwc(x, C, dtype, dev), pack_fwd(w, C, dtype, dev), pack_bwd(w, C, C, dtype, dev)
+    y = ops.conv_fwd(geom, xd, wf, b.to(dev), C, act=ACT_RELU)
+    assert rel_err(nchw(y, C), F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))) < TOL[dtype]
+    y = ops.conv_fwd(geom, xd, wf, None, C, aux=xd, epi=EPI_ADD)
+    assert rel_err(nchw(y, C), x.double() + F.conv2d(x.double(), w.double(), padding=1)) < TOL[dtype]
+    a, dy, d2 = F.relu(x), r(N, C, H, W), r(N, C, H, W)
+    dx = ops.conv_dgrad(geom, nhwc(dy, C, dtype, dev), wb, tuple(xd.shape), C, aux=nhwc(a, C, dtype, dev), epi=EPI_MUL_ACTGRAD,
+                        aux_act=ACT_RELU, aux2=nhwc(d2, C, dtype, dev))
+    ref = (F.conv_transpose2d(dy.double(), w.double(), padding=1) + d2.double()) * (a > 0).double()
+    assert rel_err(nchw(dx, C), ref) < TOL[dtype]
+    # grouped: 3 groups of 64 -> 128 with bias, LeakyReLU
+    G, ci, co = 3, 64, 128
+    xg, wg, bg = r(N, G * ci, H, W), r(G * co, ci, 3, 3) / math.sqrt(ci * 9), torch.randn(G * co, generator=g)
+    gg = ops.ConvGeom(ci, co, 3, 1, 1, groups=G, x_gstride=ci, y_gstride=co)
+    wfg = torch.stack([pack_fwd(wg[i * co:(i + 1) * co], ci, dtype, dev) for i in range(G)])
+    yg = ops.conv_fwd(gg, nhwc(xg, G * ci, dtype, dev), wfg, bg.to(dev), ci, y_pitch=G * co, act=ACT_LRELU, slope=0.2)
+    assert rel_err(nchw(yg, G * co), F.leaky_relu(F.conv2d(xg.double(), wg.double(), bg.double(), padding=1, groups=G), 0.2)) < TOL[dtype]
+    wbg = torch.stack([pack_bwd(wg[i * co:(i + 1) * co], ci, co, dtype, dev) for i in range(G)])
+    dyg = r(N, G * co, H, W)
+    dxg = ops.conv_dgrad(gg, nhwc(dyg, G * co, dtype, dev), wbg, (N, H, W, G * ci), ci)
+    refg = torch.cat([F.conv_transpose2d(dyg[:, i * co:(i + 1) * co].double(), wg[i * co:(i + 1) * co].double(), padding=1) for i in range(G)], 1)
+    assert rel_err(nchw(dxg, G * ci), refg) < TOL[dtype]
