@@ -50,7 +50,10 @@ typedef struct {
   int32_t transposed;
   int32_t reflect;
   int32_t groups;       /* >=1: batched independent convs; group g reads channels
-                           [g*x_gstride, +Cin) and writes [g*y_gstride, +Cout)          */
+                           [g*x_gstride, +Cin) and writes [g*y_gstride, +Cout).  A stride
+                           >= the pitch makes that side group-major: [groups][N][H][W][pitch]
+                           (whole tensors `stride` elements apart), e.g. the 12 gamma|beta
+                           planes of the generator, one 1-KB-row tensor per norm            */
   int32_t x_gstride, y_gstride;
 } s2p_conv_desc;
 

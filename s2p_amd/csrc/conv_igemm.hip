@@ -1353,6 +1353,14 @@ struct Geo {
   long long w_gstride; int w_row;
 };
 
+// Elements from the gathered tensor's base to the end of its last group (the buffer descriptors' extent; the kernels take
+// g * xg off for group g).  Groups either share the pixel rows (xg < xp: channel slices, the extent is one tensor) or are whole
+// tensors xg elements apart (group-major: [groups][N][H][W][xp]).
+static inline long long gathered_elems(const Geo& G) {
+  const long long one = (long long)G.N * G.Hi * G.Wi * G.xp;
+  return (G.groups > 1 && G.xg >= G.xp) ? one + (long long)(G.groups - 1) * G.xg : one;
+}
+
 // "gather" orientation: out(oy) = sum_k in(oy*stride + k - pad)   (conv fwd, convT dgrad)
 template <typename T>
 static int run_gather(const Geo& G, const void* x, const void* w, const float* bias, const void* aux,
@@ -1370,7 +1378,7 @@ static int run_gather(const Geo& G, const void* x, const void* w, const float* b
   if (a.T > MAX_TAPS) S2P_FAIL(-2, "conv: more than %d taps", MAX_TAPS);
   for (int ky = 0; ky < G.KH; ++ky)
     for (int kx = 0; kx < G.KW; ++kx) a.tap[ky * G.KW + kx] = pack_tap(ky - G.pad, kx - G.pad, ky * G.KW + kx);
-  return launch_gather<T>(a, G.groups, (long long)G.N * G.Hi * G.Wi * G.xp, st);
+  return launch_gather<T>(a, G.groups, gathered_elems(G), st);
 }
 
 // "scatter" orientation expressed per output phase: out(oy) = sum_k in((oy + pad - k)/stride)
@@ -1383,7 +1391,7 @@ static int run_scatter(const Geo& G, const void* x, const void* w, const float* 
   if constexpr (sizeof(T) == 2) {
     // all s*s phases in ONE launch of the LDS-DMA kernel (blockIdx.z = phase) when that kernel applies
     static const int no_merge = (s2p_env_set("S2P_NO_PHASE_MERGE") || s2p_env_set("S2P_NO_LDS_DMA"));
-    const long long xb = (long long)G.N * G.Hi * G.Wi * G.xp * 2, wb = (long long)G.Co * G.w_row * 2;
+    const long long xb = gathered_elems(G) * 2, wb = (long long)G.Co * G.w_row * 2;
     if (!no_merge && s * s <= MAX_PHASES && s > 1 && G.Ci % 64 == 0 && xb < (1ll << 31) && wb < (1ll << 31) && G.Cst > 32) {
       GatherArgs a{};
       a.x = x; a.w = w; a.bias = bias; a.aux = aux; a.aux2 = aux2; a.y = y;
@@ -1457,7 +1465,7 @@ static int run_scatter(const Geo& G, const void* x, const void* w, const float* 
         }
       }
       a.T = t; a.Ktot = t * G.Ci;
-      int rc = launch_gather<T>(a, G.groups, (long long)G.N * G.Hi * G.Wi * G.xp, st);
+      int rc = launch_gather<T>(a, G.groups, gathered_elems(G), st);
       if (rc) return rc;
     }
   return 0;

@@ -23,12 +23,33 @@ class ConvLayer:
         return ops.conv_fwd(self.geom, x, self.pk.w_fwd, self.pk.bias, self.cin_pad(x.dtype), y_pitch=y_pitch,
                             act=act, slope=slope, aux=aux, epi=epi)
 
+    def _group_major(self, t5):
+        """This grouped conv's geometry with the PRODUCED side group-major: t5 is [groups, N, H, W, pitch] (one whole NHWC
+        tensor per group) instead of channel slices of one wide tensor."""
+        g = self.geom
+        assert t5.dim() == 5 and t5.shape[0] == g.groups and t5.is_contiguous()
+        key = t5.stride(0)
+        gm = self.__dict__.setdefault("_gm", {})
+        if key not in gm:
+            gm[key] = ConvGeom(g.cin, g.cout, g.k, g.stride, g.pad, g.transposed, g.reflect, g.groups, g.output_padding,
+                               x_gstride=g.x_gstride, y_gstride=key)
+        return gm[key]
+
+    def fwd_group_major(self, x, out5):
+        """Grouped conv whose group g writes the whole tensor out5[g] ([groups, N, Ho, Wo, pitch])."""
+        ops.conv_fwd(self._group_major(out5), x, self.pk.w_fwd, self.pk.bias, self.cin_pad(x.dtype), y_pitch=out5.shape[4],
+                     out=out5[0])
+        return out5
+
     def fwd_mat(self, x, gb, gb_off, gb_st, st_off, act, slope, aux=None, epi=EPI_STORE):
         """conv (+ residual) -> InstanceNorm -> MAT modulation -> activation; returns (conv output, modulated, stats)."""
         return ops.conv_fwd_mat(self.geom, x, self.pk.w_fwd, self.pk.bias, self.cin_pad(x.dtype), gb, gb_off, gb_st, st_off,
                                 act=act, slope=slope, aux=aux, epi=epi)
 
     def dgrad(self, dy, x_shape, aux=None, epi=EPI_STORE, aux_act=ACT_NONE, slope=0.2, aux2=None):
+        if dy.dim() == 5:           # group-major dy ([groups, N, Ho, Wo, pitch]: see fwd_group_major)
+            return ops.conv_dgrad(self._group_major(dy), dy[0], self.pk.w_bwd, tuple(x_shape), self.cin_pad(dy.dtype), aux=aux,
+                                  epi=epi, aux_act=aux_act, slope=slope, aux2=aux2)
         return ops.conv_dgrad(self.geom, dy, self.pk.w_bwd, tuple(x_shape), self.cin_pad(dy.dtype), aux=aux, epi=epi,
                               aux_act=aux_act, slope=slope, aux2=aux2)
 
@@ -47,10 +68,15 @@ class ConvLayer:
             one = ConvGeom(g.cin, g.cout, 3, 1, 1)
             gw = self.pk.gw.view(g.groups, -1)
             gb = self.pk.gb.view(g.groups, -1) if self.pk.gb is not None else None
-            jobs = [(x, i * g.x_gstride, dy, i * g.y_gstride, gw[i], gb[i] if gb is not None else None)
-                    for i in range(g.groups)]
+            if dy.dim() == 5:       # group-major dy: one whole tensor per group
+                jobs = [(x, i * g.x_gstride, dy[i], 0, gw[i], gb[i] if gb is not None else None) for i in range(g.groups)]
+            else:
+                jobs = [(x, i * g.x_gstride, dy, i * g.y_gstride, gw[i], gb[i] if gb is not None else None)
+                        for i in range(g.groups)]
             ops.conv_wgrad_batched(one, jobs, g.cin, self.cin_real, self.cout_real)
             return
+        if dy.dim() == 5:
+            raise RuntimeError("group-major dY is only wired for the batched slab weight-gradient path (bf16, 3x3, 64-channel multiples)")
         if g.groups == 1 and g.cout == 1 and x.dtype == torch.bfloat16 and g.stride == 1 and not g.transposed and not g.reflect:
             # PatchGAN logit head: activation-stationary kernel behind the batched entry point (it needs a workspace)
             ops.conv_wgrad_batched(g, [(x, 0, dy, 0, self.pk.gw, self.pk.gb)], self.cin_pad(x.dtype), self.cin_real,

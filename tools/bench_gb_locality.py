@@ -56,6 +56,22 @@ def chain_b():
     return x
 
 
+g12n = ops.ConvGeom(NH, 2 * C, 3, 1, 1, groups=NN, x_gstride=NH, y_gstride=N * 21 * 21 * 2 * C)
+gbn = torch.empty((NN, N, 21, 21, 2 * C), dtype=dt, device=dev)
+
+
+def chain_n():
+    """A with the planes norm-major ([12][N][HW][2C], rows of 1 KB) instead of pixel-major ([N][HW][12*2C], rows of 12 KB)"""
+    ops.conv_fwd(g12n, actv, w12, b12, NH, y_pitch=2 * C, out=gbn)
+    x = x0
+    for k in range(1, NN):
+        _, x, _ = ops.conv_fwd_mat(geom, x, wf[k], b, C, gbn[k], 0, st, k * 2 * C, ACT_LRELU, 0.2)
+    return x
+
+
+def only_gb12n(): ops.conv_fwd(g12n, actv, w12, b12, NH, y_pitch=2 * C, out=gbn)
+
+
 def only_gb12(): return ops.conv_fwd(g12, actv, w12, b12, NH)
 def only_gb1():
     for k in range(1, NN): ops.conv_fwd(g1, actv_k[k], w1[k], b1[k], NH)
@@ -66,4 +82,8 @@ print("chains agree:", float((ya.float() - yb.float()).abs().max()))
 ta, tb = timeit(chain_a), timeit(chain_b)
 t12, t1 = timeit(only_gb12), timeit(only_gb1)
 print("A (12-group up front) %.1f us | B (per norm) %.1f us | gamma/beta convs alone: 12-group %.1f, 11 x one-group %.1f" % (ta, tb, t12, t1))
+yn = chain_n()
+print("norm-major chain agrees:", float((ya.float() - yn.float()).abs().max()))
+tn, t12n = timeit(chain_n), timeit(only_gb12n)
+print("N (norm-major planes) %.1f us | its 12-group conv %.1f us | fused convs %.1f us each" % (tn, t12n, (tn - t12n) / 11))
 print("fused convs in A: %.1f us each | in B: %.1f us each" % ((ta - t12) / 11, (tb - t1) / 11))
