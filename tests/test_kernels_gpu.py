@@ -756,3 +756,25 @@ def test_conv_plane_kernels_epilogues_and_groups(hip_device, N, HW_):
     dxg = ops.conv_dgrad(gg, nhwc(dyg, G * co, dtype, dev), wbg, (N, H, W, G * ci), ci)
     refg = torch.cat([F.conv_transpose2d(dyg[:, i * co:(i + 1) * co].double(), wg[i * co:(i + 1) * co].double(), padding=1) for i in range(G)], 1)
     assert rel_err(nchw(dxg, G * ci), refg) < TOL[dtype]
+    # the same grouped conv with its produced side GROUP-MAJOR ([G][N][H][W][co]: group stride >= pitch, the layout of the
+    # generator's gamma|beta planes): forward writes it, dgrad and the batched weight gradient read it -- same bits
+    ggm = ops.ConvGeom(ci, co, 3, 1, 1, groups=G, x_gstride=ci, y_gstride=N * H * W * co)
+    y5 = torch.full((G, N, H, W, co), float("nan"), dtype=dtype, device=dev)
+    ops.conv_fwd(ggm, nhwc(xg, G * ci, dtype, dev), wfg, bg.to(dev), ci, y_pitch=co, act=ACT_LRELU, slope=0.2, out=y5[0])
+    for i in range(G):
+        assert torch.equal(y5[i], yg[..., i * co:(i + 1) * co])
+    dy_il = nhwc(dyg, G * co, dtype, dev)
+    dy5 = torch.stack([dy_il[..., i * co:(i + 1) * co] for i in range(G)]).contiguous()
+    dx5 = ops.conv_dgrad(ggm, dy5[0], wbg, (N, H, W, G * ci), ci)
+    assert torch.equal(dx5, dxg)
+    one = ops.ConvGeom(ci, co, 3, 1, 1)
+    xil = nhwc(xg, G * ci, dtype, dev)
+    dw_a = torch.zeros(G, co * 9 * ci, device=dev); db_a = torch.zeros(G, co, device=dev)
+    dw_b = torch.zeros_like(dw_a); db_b = torch.zeros_like(db_a)
+    ops.conv_wgrad_batched(one, [(xil, i * ci, dy_il, i * co, dw_a[i], db_a[i]) for i in range(G)], ci, ci, co)
+    ops.conv_wgrad_batched(one, [(xil, i * ci, dy5[i], 0, dw_b[i], db_b[i]) for i in range(G)], ci, ci, co)
+    torch.cuda.synchronize()
+    assert torch.equal(dw_a, dw_b) and torch.equal(db_a, db_b)
+    refw = torch.cat([torch.autograd.grad(F.conv2d(xg[:, i * ci:(i + 1) * ci].double(), wv, padding=1), wv, dyg[:, i * co:(i + 1) * co].double())[0]
+                      for i in range(G) for wv in [wg[i * co:(i + 1) * co].double().requires_grad_(True)]])
+    assert rel_err(dw_b.view(G * co, 3, 3, ci).permute(0, 3, 1, 2).cpu(), refw) < TOL[dtype]
