@@ -11,6 +11,7 @@
 //   sums   : opaque fp32 buffer [N][C][S][4] of per-split backward sums, summed by the consumer in split order.
 //   y  = act( xhat * (1 + g_img + g_st) + (b_img + b_st) ),   xhat = (x - mean) * rstd
 #include "s2p_common.h"
+#include <type_traits>
 
 struct NormArgs {
   const void* x; const void* da; const void* gb; const float* gbst; const float* stats; float* sums;
@@ -278,12 +279,15 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const NormArgs a) {
 // (mean, then centred second moment) with wave shuffles + LDS, and applies the modulation from registers: x is read
 // once instead of twice and the statistics pass is not a separate launch.  It also writes the statistics buffer in
 // the usual self-describing format (one split), so the backward kernels consume it unchanged.
-template <typename T, int CS>          // CS = channels per workgroup: 64 (full 128-byte bf16 lines) or 32 (twice the workgroups)
-__global__ __launch_bounds__(1024) void in_fused_fwd_kernel(const NormArgs a) {
+// TH = 256 is the form for the SMALL planes (PatchGAN 7x7 .. 13x13 maps, plain InstanceNorm: GB = false): 8 chunks per thread,
+// planes of <= 256 (bf16) / 128 (fp32) pixels.  A 1024-thread workgroup leaves most of its lanes without a pixel there and only
+// two workgroups fit a CU, so load, reduce and store phases hardly overlap; eight 256-thread workgroups per CU do.
+template <typename T, int CS, int TH = 1024, bool GB = true>   // CS = channels per workgroup: 64 (full 128-byte bf16 lines) or 32 (twice the workgroups)
+__global__ __launch_bounds__(TH) void in_fused_fwd_kernel(const NormArgs a) {
   constexpr int CE = DT<T>::CE;
-  constexpr int NCH = CS / CE, PR = 1024 / NCH, MAXP = (DT<T>::CE == 8 ? 512 : 256) / PR;   // planes of <= 512 (bf16) / 256 (fp32) pixels
-  constexpr int RPW = 64 / NCH;
-  __shared__ float red[16][CS];
+  constexpr int NCH = CS / CE, PR = TH / NCH, MAXP = TH == 1024 ? (DT<T>::CE == 8 ? 512 : 256) / PR : 8;   // TH 1024: planes of <= 512 (bf16) / 256 (fp32) pixels
+  constexpr int RPW = 64 / NCH, NW = TH / 64, MG = GB ? MAXP : 1;
+  __shared__ float red[NW][CS];
   __shared__ float cst[4][CS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cc = tid % NCH, pr = tid / NCH;
@@ -293,15 +297,16 @@ __global__ __launch_bounds__(1024) void in_fused_fwd_kernel(const NormArgs a) {
   const bool cok = c0 < a.C;
   const size_t img = (size_t)n * a.HW;
   const T* xb = (const T*)a.x + img * a.x_pitch + c0;
-  const T* gbb = a.gb ? (const T*)a.gb + img * a.gb_pitch + c0 : nullptr;
-  Chunk<T> xv[MAXP], gv[MAXP], bv[MAXP];
+  const T* gbb = (GB && a.gb) ? (const T*)a.gb + img * a.gb_pitch + c0 : nullptr;
+  Chunk<T> xv[MAXP], gv[MG], bv[MG];
 #pragma unroll
   for (int k = 0; k < MAXP; ++k) {
     const int p = pr + k * PR;
-    xv[k].raw = (u32x4){0u, 0u, 0u, 0u}; gv[k].raw = xv[k].raw; bv[k].raw = xv[k].raw;
+    xv[k].raw = (u32x4){0u, 0u, 0u, 0u};
+    if (GB) { gv[k % MG].raw = xv[k].raw; bv[k % MG].raw = xv[k].raw; }
     if (cok && p < a.HW) {
       xv[k].raw = *(const u32x4*)(xb + (size_t)p * a.x_pitch);
-      if (gbb) { gv[k].raw = *(const u32x4*)(gbb + (size_t)p * a.gb_pitch); bv[k].raw = *(const u32x4*)(gbb + (size_t)p * a.gb_pitch + a.C); }
+      if (GB && gbb) { gv[k % MG].raw = *(const u32x4*)(gbb + (size_t)p * a.gb_pitch); bv[k % MG].raw = *(const u32x4*)(gbb + (size_t)p * a.gb_pitch + a.C); }
     }
   }
   // sum over the pixel rows of a wave (lanes that share cc differ in the lane bits above log2(NCH)), then over waves
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(1024) void in_fused_fwd_kernel(const NormArgs a) {
     if (tid < CS) {
       float t = 0.f;
 #pragma unroll
-      for (int w = 0; w < 16; ++w) t += red[w][tid];
+      for (int w = 0; w < NW; ++w) t += red[w][tid];
       cst[slot][tid] = t;
     }
     __syncthreads();
@@ -373,8 +378,8 @@ __global__ __launch_bounds__(1024) void in_fused_fwd_kernel(const NormArgs a) {
     Chunk<T> o0;
 #pragma unroll
     for (int e = 0; e < CE; ++e) {
-      float gg = gs[e] + (gbb ? gv[k].get(e) : 0.f);
-      float bb = bs[e] + (gbb ? bv[k].get(e) : 0.f);
+      float gg = gs[e] + ((GB && gbb) ? gv[k % MG].get(e) : 0.f);
+      float bb = bs[e] + ((GB && gbb) ? bv[k % MG].get(e) : 0.f);
       float xh;
       float yv = mat_value(xv[k].get(e), mean[e], rstd[e], gg, bb, xh);
       o0.set(e, yv > 0.f ? yv : yv * ns);
@@ -388,11 +393,13 @@ __global__ __launch_bounds__(1024) void in_fused_fwd_kernel(const NormArgs a) {
 // sums (wave shuffles + LDS, fixed order) and then writes dx, d(gamma_img | beta_img) and the state-affine gradient from
 // the registers: one launch and one read of every tensor instead of the reduce + apply pair (each tensor read twice).
 // Per-channel constants stay in LDS and are re-read per use (keeps the kernel under the 128-VGPR budget of 16 waves / CU).
-template <typename T, int CS>
-__global__ __launch_bounds__(1024) void in_fused_bwd_kernel(const NormArgs a) {
+template <typename T, int CS, int TH = 1024, bool GB = true>      // TH = 256, GB = false: the small-plane form (see in_fused_fwd_kernel)
+__global__ __launch_bounds__(TH) void in_fused_bwd_kernel(const NormArgs a) {
   constexpr int CE = DT<T>::CE;
-  constexpr int NCH = CS / CE, PR = 1024 / NCH, MAXP = (DT<T>::CE == 8 ? 512 : 256) / PR;
-  __shared__ float red[4][16][CS];
+  constexpr int NCH = CS / CE, PR = TH / NCH, MAXP = TH == 1024 ? (DT<T>::CE == 8 ? 512 : 256) / PR : 8;
+  constexpr int NW = TH / 64, MG = GB ? MAXP : 1;
+  typedef typename std::conditional<(MAXP * CE > 32), unsigned long long, unsigned>::type mask_t;
+  __shared__ float red[4][NW][CS];
   __shared__ __attribute__((aligned(16))) float cst[6][CS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cc = tid % NCH, pr = tid / NCH;
@@ -404,17 +411,18 @@ __global__ __launch_bounds__(1024) void in_fused_bwd_kernel(const NormArgs a) {
   const int cb0 = slab * CS;
   const T* xb = (const T*)a.x + img * a.x_pitch + cb0;
   const T* dab = (const T*)a.da + img * a.da_pitch + cb0;
-  const T* gbb = a.gb ? (const T*)a.gb + img * a.gb_pitch + cb0 : nullptr;
+  const T* gbb = (GB && a.gb) ? (const T*)a.gb + img * a.gb_pitch + cb0 : nullptr;
   const int lc = cc * CE;
-  Chunk<T> xv[MAXP], dv[MAXP], gv[MAXP], bv[MAXP];
+  Chunk<T> xv[MAXP], dv[MAXP], gv[MG], bv[MG];
 #pragma unroll
   for (int k = 0; k < MAXP; ++k) {
     const int p = pr + k * PR;
-    xv[k].raw = (u32x4){0u, 0u, 0u, 0u}; dv[k].raw = xv[k].raw; gv[k].raw = xv[k].raw; bv[k].raw = xv[k].raw;
+    xv[k].raw = (u32x4){0u, 0u, 0u, 0u}; dv[k].raw = xv[k].raw;
+    if (GB) { gv[k % MG].raw = xv[k].raw; bv[k % MG].raw = xv[k].raw; }
     if (cok && p < a.HW) {
       xv[k].raw = *(const u32x4*)(xb + (p * a.x_pitch + lc));
       dv[k].raw = *(const u32x4*)(dab + (p * a.da_pitch + lc));
-      if (gbb) { gv[k].raw = *(const u32x4*)(gbb + (p * a.gb_pitch + lc)); bv[k].raw = *(const u32x4*)(gbb + (p * a.gb_pitch + lc + a.C)); }
+      if (GB && gbb) { gv[k % MG].raw = *(const u32x4*)(gbb + (p * a.gb_pitch + lc)); bv[k % MG].raw = *(const u32x4*)(gbb + (p * a.gb_pitch + lc + a.C)); }
     }
   }
   if (tid < CS) {
@@ -428,7 +436,7 @@ __global__ __launch_bounds__(1024) void in_fused_bwd_kernel(const NormArgs a) {
   }
   __syncthreads();
   const float gneg = a.act == S2P_ACT_RELU ? 0.f : (a.act == S2P_ACT_LRELU ? a.slope : 1.f);
-  unsigned posmask = 0u;
+  mask_t posmask = 0;
   // ---- pass 1: plane sums.  Pixels beyond HW were loaded as zeros: their dL/dy is 0, so they add nothing.
 #pragma unroll
   for (int e = 0; e < CE; ++e) {
@@ -437,11 +445,11 @@ __global__ __launch_bounds__(1024) void in_fused_bwd_kernel(const NormArgs a) {
     float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) {
-      const float gg = g1 + (gbb ? gv[k].get(e) : 0.f), bb = b1 + (gbb ? bv[k].get(e) : 0.f);
+      const float gg = g1 + ((GB && gbb) ? gv[k % MG].get(e) : 0.f), bb = b1 + ((GB && gbb) ? bv[k % MG].get(e) : 0.f);
       float xh;
       const float yv = mat_value(xv[k].get(e), m, r, gg, bb, xh);
       const bool pos = yv > 0.f;
-      posmask |= pos ? (1u << (k * CE + e)) : 0u;           // pass 2 takes the branch from here: beta is dead after pass 1
+      posmask |= pos ? ((mask_t)1 << (k * CE + e)) : (mask_t)0;           // pass 2 takes the branch from here: beta is dead after pass 1
       const float dy = dv[k].get(e) * (pos ? 1.f : gneg);
       const float dxh = dy * gg;
       q0 += dxh; q1 += dxh * xh; q2 += dy * xh; q3 += dy;
@@ -457,7 +465,7 @@ __global__ __launch_bounds__(1024) void in_fused_bwd_kernel(const NormArgs a) {
   if (tid < CS) {
     float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) { t0 += red[0][w][tid]; t1 += red[1][w][tid]; t2 += red[2][w][tid]; t3 += red[3][w][tid]; }
+    for (int w = 0; w < NW; ++w) { t0 += red[0][w][tid]; t1 += red[1][w][tid]; t2 += red[2][w][tid]; t3 += red[3][w][tid]; }
     const float inv = 1.f / (float)a.HW;
     cst[4][tid] = t0 * inv; cst[5][tid] = t1 * inv;
     const int c = slab * CS + tid;
@@ -484,9 +492,9 @@ __global__ __launch_bounds__(1024) void in_fused_bwd_kernel(const NormArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int e = 4 * h4 + j;
-        const float gg = g4[j] + (gbb ? gv[k].get(e) : 0.f);
+        const float gg = g4[j] + ((GB && gbb) ? gv[k % MG].get(e) : 0.f);
         const float xh = (xv[k].get(e) - m4[j]) * r4[j];
-        const float dy = dv[k].get(e) * (((posmask >> (k * CE + e)) & 1u) ? 1.f : gneg);
+        const float dy = dv[k].get(e) * (((posmask >> (k * CE + e)) & (mask_t)1) ? 1.f : gneg);
         const float dxh = dy * gg;
         o0.set(e, r4[j] * (dxh - s14[j] - xh * s24[j]));
         o1.set(e, dy * xh);
@@ -614,6 +622,12 @@ extern "C" int s2p_in_apply_fwd(int dtype, const void* x, int N, int HW, int C, 
   return launch_apply<0>(dtype, a, (hipStream_t)stream);
 }
 
+// the 256-thread form of the fused kernels: plain InstanceNorm (no gamma/beta maps) on planes of <= 256 (bf16) / 128 (fp32) pixels
+static inline bool small_plane(int dtype, int HW, const void* gb_img) {
+  static const int off = s2p_env_set("S2P_NORM_NO_SMALL");          // A/B switch (diagnostics build only)
+  return !off && !gb_img && HW <= (dtype == S2P_F32 ? 128 : 256);
+}
+
 // statistics + apply in one call: one fused launch for small planes, otherwise the two-kernel path
 extern "C" int s2p_in_norm_fwd(int dtype, const void* x, int N, int HW, int C, int pitch, const void* gb_img, int gb_pitch,
                                const float* gb_st, int gb_st_pitch, int act, float slope, float eps, void* y, int y_pitch,
@@ -634,6 +648,12 @@ extern "C" int s2p_in_norm_fwd(int dtype, const void* x, int N, int HW, int C, i
   const bool half = s2p_env_set("S2P_NORM_CS32") && C % 32 == 0;
   dim3 grid(N, cdiv(C, half ? 32 : 64));
   hipStream_t st = (hipStream_t)stream;
+  if (small_plane(dtype, HW, gb_img)) {
+    if (dtype == S2P_F32) hipLaunchKernelGGL((in_fused_fwd_kernel<float, 64, 256, false>), dim3(N, cdiv(C, 64)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((in_fused_fwd_kernel<__bf16, 64, 256, false>), dim3(N, cdiv(C, 64)), dim3(256), 0, st, a);
+    S2P_CHECK_LAUNCH("in_fused_fwd_kernel (small planes)");
+    return 0;
+  }
   if (dtype == S2P_F32) { if (half) hipLaunchKernelGGL((in_fused_fwd_kernel<float, 32>), grid, dim3(1024), 0, st, a);
                           else hipLaunchKernelGGL((in_fused_fwd_kernel<float, 64>), grid, dim3(1024), 0, st, a); }
   else { if (half) hipLaunchKernelGGL((in_fused_fwd_kernel<__bf16, 32>), grid, dim3(1024), 0, st, a);
@@ -708,6 +728,12 @@ extern "C" int s2p_in_norm_bwd_res(int dtype, const void* da, int da_pitch, cons
   const bool half = s2p_env_set("S2P_NORM_CS32") && C % 32 == 0;
   dim3 grid(N, cdiv(C, half ? 32 : 64));
   hipStream_t st = (hipStream_t)stream;
+  if (small_plane(dtype, HW, gb_img) && !dgb_img) {
+    if (dtype == S2P_F32) hipLaunchKernelGGL((in_fused_bwd_kernel<float, 64, 256, false>), dim3(N, cdiv(C, 64)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((in_fused_bwd_kernel<__bf16, 64, 256, false>), dim3(N, cdiv(C, 64)), dim3(256), 0, st, a);
+    S2P_CHECK_LAUNCH("in_fused_bwd_kernel (small planes)");
+    return 0;
+  }
   if (dtype == S2P_F32) { if (half) hipLaunchKernelGGL((in_fused_bwd_kernel<float, 32>), grid, dim3(1024), 0, st, a);
                           else hipLaunchKernelGGL((in_fused_bwd_kernel<float, 64>), grid, dim3(1024), 0, st, a); }
   else { if (half) hipLaunchKernelGGL((in_fused_bwd_kernel<__bf16, 32>), grid, dim3(1024), 0, st, a);

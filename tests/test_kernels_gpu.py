@@ -244,6 +244,39 @@ def test_instance_norm_mat(hip_device, dtype, modulated):
     assert torch.equal(stats, stats2) and torch.equal(y, y2) and torch.equal(dx, dx2)
 
 
+@pytest.mark.parametrize("dtype,shape", [(torch.bfloat16, (5, 256, 7, 7)), (torch.bfloat16, (3, 512, 8, 8)), (torch.bfloat16, (4, 256, 12, 12)),
+                                         (torch.bfloat16, (3, 512, 13, 13)), (torch.bfloat16, (2, 72, 16, 16)), (torch.bfloat16, (2, 64, 16, 17)),
+                                         (torch.float32, (3, 132, 8, 16)), (torch.float32, (2, 64, 11, 12))])
+def test_instance_norm_small_planes(hip_device, dtype, shape):
+    """The PatchGAN maps (7x7 .. 13x13, plain InstanceNorm + LeakyReLU): planes of <= 256 (bf16) / 128 (fp32) pixels take the
+    256-thread form of the fused forward / backward kernels; one size above each limit takes the 1024-thread form.  Against
+    float64, and against the two-kernel path (statistics + apply) on the same inputs."""
+    dev = hip_device
+    g = torch.Generator().manual_seed(23)
+    N, C, H, W = shape
+    x = torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3
+    da = torch.randn(N, C, H, W, generator=g)
+    if dtype == torch.bfloat16:
+        x, da = x.bfloat16().float(), da.bfloat16().float()
+    xr = x.double().requires_grad_(True)
+    y_ref = F.leaky_relu(F.instance_norm(xr, eps=1e-5), 0.2)
+    y_ref.backward(da.double())
+    xd, dad = nhwc(x, C, dtype, dev), nhwc(da, C, dtype, dev)
+    y, stats = ops.in_norm_fwd(xd, C, act=ACT_LRELU, slope=0.2)
+    dx = ops.in_bwd(dad, xd, C, stats, act=ACT_LRELU, slope=0.2)
+    torch.cuda.synchronize()
+    tol = TOL[dtype]
+    assert rel_err(nchw(y, C), y_ref.detach()) < tol
+    assert rel_err(nchw(dx, C), xr.grad) < tol * 2
+    stats2 = ops.in_stats(xd, C)
+    y2 = ops.in_apply_fwd(xd, C, stats2, act=ACT_LRELU, slope=0.2)
+    assert rel_err(y.float().cpu(), y2.float().cpu().double()) < (1e-5 if dtype == torch.float32 else 1e-2)
+    y3, stats3 = ops.in_norm_fwd(xd, C, act=ACT_LRELU, slope=0.2)
+    dx3 = ops.in_bwd(dad, xd, C, stats3, act=ACT_LRELU, slope=0.2)
+    nst = 4 + N * C * 2             # header + one {mean, M2} pair per (image, channel): what the fused launch writes of the buffer
+    assert torch.equal(y, y3) and torch.equal(stats[:nst], stats3[:nst]) and torch.equal(dx, dx3)          # no atomics: same bits again
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 21, 21), (1, 64, 84, 84), (3, 68, 9, 7), (2, 132, 16, 16)])
 def test_instance_norm_large_mean(hip_device, shape):
     """|mean| / std = 1e3 (a near-constant, strongly biased channel): single-pass raw moments E[x^2] - E[x]^2 lose all
