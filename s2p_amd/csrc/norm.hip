@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const NormArgs a) {
 template <typename T, int CS, int TH = 1024, bool GB = true>   // CS = channels per workgroup: 64 (full 128-byte bf16 lines) or 32 (twice the workgroups)
 __global__ __launch_bounds__(TH) void in_fused_fwd_kernel(const NormArgs a) {
   constexpr int CE = DT<T>::CE;
-  constexpr int NCH = CS / CE, PR = TH / NCH, MAXP = TH == 1024 ? (DT<T>::CE == 8 ? 512 : 256) / PR : 8;   // TH 1024: planes of <= 512 (bf16) / 256 (fp32) pixels
+  constexpr int NCH = CS / CE, PR = TH / NCH, MAXP = TH == 1024 ? (DT<T>::CE == 8 ? 512 : 256) / PR : 8;   // TH 1024: planes of <= 512 (bf16) / 256 (fp32) pixels; TH 512 the same with 8 chunks per thread
   constexpr int RPW = 64 / NCH, NW = TH / 64, MG = GB ? MAXP : 1;
   __shared__ float red[NW][CS];
   __shared__ float cst[4][CS];
@@ -623,9 +623,13 @@ extern "C" int s2p_in_apply_fwd(int dtype, const void* x, int N, int HW, int C, 
 }
 
 // the 256-thread form of the fused kernels: plain InstanceNorm (no gamma/beta maps) on planes of <= 256 (bf16) / 128 (fp32) pixels
-static inline bool small_plane(int dtype, int HW, const void* gb_img) {
-  static const int off = s2p_env_set("S2P_NORM_NO_SMALL");          // A/B switch (diagnostics build only)
-  return !off && !gb_img && HW <= (dtype == S2P_F32 ? 128 : 256);
+// (returns the workgroup size: 256, 512 for up to twice those planes, or 0: the 1024-thread form)
+static inline int small_plane(int dtype, int HW, const void* gb_img) {
+  static const int off = s2p_env_set("S2P_NORM_NO_SMALL");          // A/B switches (diagnostics build only)
+  static const int no512 = s2p_env_set("S2P_NORM_NO_512");
+  if (off || gb_img) return 0;
+  const int lim = dtype == S2P_F32 ? 128 : 256;
+  return HW <= lim ? 256 : (HW <= 2 * lim && !no512 ? 512 : 0);
 }
 
 // statistics + apply in one call: one fused launch for small planes, otherwise the two-kernel path
@@ -648,9 +652,12 @@ extern "C" int s2p_in_norm_fwd(int dtype, const void* x, int N, int HW, int C, i
   const bool half = s2p_env_set("S2P_NORM_CS32") && C % 32 == 0;
   dim3 grid(N, cdiv(C, half ? 32 : 64));
   hipStream_t st = (hipStream_t)stream;
-  if (small_plane(dtype, HW, gb_img)) {
-    if (dtype == S2P_F32) hipLaunchKernelGGL((in_fused_fwd_kernel<float, 64, 256, false>), dim3(N, cdiv(C, 64)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((in_fused_fwd_kernel<__bf16, 64, 256, false>), dim3(N, cdiv(C, 64)), dim3(256), 0, st, a);
+  if (const int th = small_plane(dtype, HW, gb_img)) {
+    const dim3 sg(N, cdiv(C, 64));
+    if (th == 256) { if (dtype == S2P_F32) hipLaunchKernelGGL((in_fused_fwd_kernel<float, 64, 256, false>), sg, dim3(256), 0, st, a);
+                     else hipLaunchKernelGGL((in_fused_fwd_kernel<__bf16, 64, 256, false>), sg, dim3(256), 0, st, a); }
+    else { if (dtype == S2P_F32) hipLaunchKernelGGL((in_fused_fwd_kernel<float, 64, 512, false>), sg, dim3(512), 0, st, a);
+           else hipLaunchKernelGGL((in_fused_fwd_kernel<__bf16, 64, 512, false>), sg, dim3(512), 0, st, a); }
     S2P_CHECK_LAUNCH("in_fused_fwd_kernel (small planes)");
     return 0;
   }
@@ -728,9 +735,12 @@ extern "C" int s2p_in_norm_bwd_res(int dtype, const void* da, int da_pitch, cons
   const bool half = s2p_env_set("S2P_NORM_CS32") && C % 32 == 0;
   dim3 grid(N, cdiv(C, half ? 32 : 64));
   hipStream_t st = (hipStream_t)stream;
-  if (small_plane(dtype, HW, gb_img) && !dgb_img) {
-    if (dtype == S2P_F32) hipLaunchKernelGGL((in_fused_bwd_kernel<float, 64, 256, false>), dim3(N, cdiv(C, 64)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((in_fused_bwd_kernel<__bf16, 64, 256, false>), dim3(N, cdiv(C, 64)), dim3(256), 0, st, a);
+  if (const int th = dgb_img ? 0 : small_plane(dtype, HW, gb_img)) {
+    const dim3 sg(N, cdiv(C, 64));
+    if (th == 256) { if (dtype == S2P_F32) hipLaunchKernelGGL((in_fused_bwd_kernel<float, 64, 256, false>), sg, dim3(256), 0, st, a);
+                     else hipLaunchKernelGGL((in_fused_bwd_kernel<__bf16, 64, 256, false>), sg, dim3(256), 0, st, a); }
+    else { if (dtype == S2P_F32) hipLaunchKernelGGL((in_fused_bwd_kernel<float, 64, 512, false>), sg, dim3(512), 0, st, a);
+           else hipLaunchKernelGGL((in_fused_bwd_kernel<__bf16, 64, 512, false>), sg, dim3(512), 0, st, a); }
     S2P_CHECK_LAUNCH("in_fused_bwd_kernel (small planes)");
     return 0;
   }

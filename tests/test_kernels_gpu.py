@@ -246,10 +246,11 @@ def test_instance_norm_mat(hip_device, dtype, modulated):
 
 @pytest.mark.parametrize("dtype,shape", [(torch.bfloat16, (5, 256, 7, 7)), (torch.bfloat16, (3, 512, 8, 8)), (torch.bfloat16, (4, 256, 12, 12)),
                                          (torch.bfloat16, (3, 512, 13, 13)), (torch.bfloat16, (2, 72, 16, 16)), (torch.bfloat16, (2, 64, 16, 17)),
-                                         (torch.float32, (3, 132, 8, 16)), (torch.float32, (2, 64, 11, 12))])
+                                         (torch.bfloat16, (3, 128, 22, 22)), (torch.bfloat16, (2, 64, 22, 23)),
+                                         (torch.float32, (3, 132, 8, 16)), (torch.float32, (2, 64, 11, 12)), (torch.float32, (2, 68, 16, 16))])
 def test_instance_norm_small_planes(hip_device, dtype, shape):
     """The PatchGAN maps (7x7 .. 13x13, plain InstanceNorm + LeakyReLU): planes of <= 256 (bf16) / 128 (fp32) pixels take the
-    256-thread form of the fused forward / backward kernels; one size above each limit takes the 1024-thread form.  Against
+    256-thread form of the fused forward / backward kernels, up to twice that the 512-thread form, 22x23 the 1024-thread form.  Against
     float64, and against the two-kernel path (statistics + apply) on the same inputs."""
     dev = hip_device
     g = torch.Generator().manual_seed(23)

@@ -1,5 +1,5 @@
 """PatchGAN InstanceNorm + LeakyReLU launches (plain IN, small planes), forward and backward, us per call from a hipGraph
-over rotating buffers (nothing stays cache-resident).  A/B: S2P_LIB=.../libs2p_hip_diag.so [S2P_NORM_NO_SMALL=1]."""
+over rotating buffers (nothing stays cache-resident).  A/B: S2P_LIB=.../libs2p_hip_diag.so [S2P_NORM_NO_SMALL=1 | S2P_NORM_NO_512=1]."""
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import torch
@@ -24,7 +24,7 @@ def timeit(fn, n=K):
 
 
 tot_f = tot_b = 0.0
-for (N, H, W, C, per_step) in [(64, 22, 22, 128, 5), (64, 12, 12, 256, 5), (64, 13, 13, 512, 5), (64, 12, 12, 128, 5), (64, 7, 7, 256, 5), (64, 8, 8, 512, 5)]:
+for (N, H, W, C, per_step) in [(64, 22, 22, 128, 5), (64, 21, 21, 256, 1), (64, 12, 12, 256, 5), (64, 13, 13, 512, 5), (64, 12, 12, 128, 5), (64, 7, 7, 256, 5), (64, 8, 8, 512, 5)]:
     xs = [torch.randn(N, H, W, C, device=dev).to(dt) for _ in range(K)]
     ds = [torch.randn(N, H, W, C, device=dev).to(dt) for _ in range(K)]
     _, st = ops.in_norm_fwd(xs[0], C, act=ACT_LRELU, slope=0.2)
