@@ -698,11 +698,13 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const GatherArgs a) {
 // y[m][co] = epilogue(bias[co] + sum_z part[z][co][m]) for the K-split launches of conv_dma_kernel: the same bias /
 // activation / residual / producer-activation-gradient semantics as conv_epilogue, element by element.  One thread per
 // (pixel, 8-channel chunk), pixels fastest: the partial reads are coalesced, the 16-B stores land in L2.
-__global__ __launch_bounds__(256) void conv_part_reduce_kernel(const GatherArgs a) {
+__global__ __launch_bounds__(64) void conv_part_reduce_kernel(const GatherArgs a) {
   typedef __bf16 T;
-  // one thread per (4 consecutive pixels, 8-channel chunk), pixel groups fastest: 16-B partial loads, coalesced
+  // one thread per (4 consecutive pixels, 8-channel chunk), pixel groups fastest: 16-B partial loads, coalesced.  The launch is
+  // small (e.g. 25 k threads) and latency-bound: one-wave workgroups spread it over every CU, and the slices are loaded four at
+  // a time (32 loads in flight per thread) but still added in slice order
   const int m4n = a.part_m >> 2;                         // part_m is a multiple of 128
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long idx = (long long)blockIdx.x * 64 + threadIdx.x;
   const int nch = (a.Cst + 7) / 8;
   if (idx >= (long long)m4n * nch) return;
   const int ch = (int)(idx / m4n), m0 = (int)(idx - (long long)ch * m4n) * 4;
@@ -715,8 +717,22 @@ __global__ __launch_bounds__(256) void conv_part_reduce_kernel(const GatherArgs 
     v[e] = (f32x4){bv, bv, bv, bv};
   }
   const size_t zs = (size_t)a.Cst * a.part_m;
-  for (int z = 0; z < a.psplit; ++z) {
-    const float* P = a.part + z * zs + (size_t)co0 * a.part_m + m0;
+  const float* P0 = a.part + (size_t)co0 * a.part_m + m0;
+  int z = 0;
+  for (; z + 4 <= a.psplit; z += 4) {
+    f32x4 t[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        t[u][e] = (co0 + e < a.Cst) ? *(const f32x4*)(P0 + (z + u) * zs + (size_t)e * a.part_m) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += t[u][e];
+  }
+  for (; z < a.psplit; ++z) {
+    const float* P = P0 + z * zs;
 #pragma unroll
     for (int e = 0; e < 8; ++e)
       if (co0 + e < a.Cst) v[e] += *(const f32x4*)(P + (size_t)e * a.part_m);
@@ -767,9 +783,11 @@ __global__ __launch_bounds__(256) void conv_part_reduce_kernel(const GatherArgs 
 
 // K-split plan of a single-phase bf16 launch (1 = no split): only launches of <= 160 workgroups, >= 16 K steps per slice
 static int conv_split_plan(int nwg, int nk) {
-  if (nwg > 160 || nk < 32) return 1;
+  static const int min_steps = s2p_env_int("S2P_SPLIT_MIN_STEPS", 16);      // A/B switch (diagnostics build only)
+  static const int max_wg = s2p_env_int("S2P_SPLIT_MAX_WG", 160);
+  if (nwg > max_wg || nk < 2 * min_steps) return 1;
   int S = 384 / nwg;
-  if (S > nk / 16) S = nk / 16;
+  if (S > nk / min_steps) S = nk / min_steps;
   if (S > 16) S = 16;
   return S < 2 ? 1 : S;
 }
@@ -1312,7 +1330,7 @@ static int launch_fast(GatherArgs& a, int groups, hipStream_t st) {
         hipLaunchKernelGGL((conv_dma_kernel<BCO, BPIX, WCO, WPIX>), grid, dim3(256), 0, st, a);
         S2P_CHECK_LAUNCH("conv_dma_kernel(split)");
         const long long n = (long long)(a.part_m / 4) * ((a.Cst + 7) / 8);
-        hipLaunchKernelGGL(conv_part_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(conv_part_reduce_kernel, dim3(cdiv(n, 64)), dim3(64), 0, st, a);
         S2P_CHECK_LAUNCH("conv_part_reduce_kernel");
         return 0;
       }
