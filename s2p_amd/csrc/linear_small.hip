@@ -1,11 +1,15 @@
 // The state path: positional encoding -> 4 x (Linear + LeakyReLU) -> per-norm affine
 // Linear(256 -> 12*2C), all fp32, M = batch (64) rows.  0.6 MFLOP per image: these layers are LATENCY-bound, and the
 // generic implicit-GEMM conv kernel spends ~45 us per layer on them (2 workgroups, a 16..23-step staged K loop).
-// Here a layer is one short launch of many small workgroups:
-//   forward / dgrad : y[M][N] = f(x)[M][Kr] . W[N][Kr]^T (+ bias, activation)   tile = 64 rows x 16 columns per workgroup,
-//                     a thread owns 4 rows x 1 column; optional split of the reduction Kr over blockIdx.z with partial
-//                     tiles in a workspace and a fixed-order reduce (the 6144-deep dgrad of the affine layer);
-//   wgrad (+ bias)  : dW[N][K] += sum_m dpre[m][n] x[m][k]                       tile = 16 n x 64 k, loop over the batch;
+// Here a layer is one short launch of many small workgroups, on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: fp32 operands,
+// fp32 accumulate), operands straight from global memory into the MFMA registers -- NO LDS at all (round 3; the LDS-staged
+// VALU form these replaced took ~20 us per layer, and it was the kernel family the LDS co-residency hazard of DESIGN.md
+// section 4 was found on: a kernel without LDS accesses is outside that class by construction):
+//   forward / dgrad : y[M][N] = f(x)[M][Kr] . W[N][Kr]^T (+ bias, activation)   a wave owns a 16 x 16 tile, a workgroup the
+//                     four 16-row tiles of a 64-row block (they share the W rows); optional split of the reduction Kr over
+//                     blockIdx.z with partial tiles in a workspace and a fixed-order reduce (the 6144-deep dgrad of the
+//                     affine layer);
+//   wgrad (+ bias)  : dW[N][K] += sum_m dpre[m][n] x[m][k]                       a wave owns 16 n x 16 k, loop over the batch;
 // where f / dpre fold the LeakyReLU derivative of the layer's saved OUTPUT into the operand staging, so the backward of a
 // layer is two short launches (wgrad + bias grad; dgrad) -- no act_bwd pass, no atomics, fixed summation order.
 // (One launch per layer, not one per chain: a layer needs every output of the previous one, and on this chip a kernel
@@ -23,6 +27,109 @@ struct LinArgs {
   int K, xin_pitch, dy_pitch, yact_pitch, dw_row, k_real;
 };
 
+__device__ __forceinline__ float lin_actgrad(float yv, int act, float slope) {
+  return act == S2P_ACT_LRELU ? (yv > 0.f ? 1.f : slope) : (act == S2P_ACT_RELU ? (yv > 0.f ? 1.f : 0.f) : 1.f);
+}
+
+// y tile of  x'[M][Kr] . W[N][Kr]^T,  x' = x * act'(xact) when xact != nullptr.
+// MFMA 16x16x4 f32 operand layout: lane l = 16 j + i holds A[row i][k j] and B[k j][col i]; the result register r of lane l is
+// D[row 4 j + r][col i].  A k-chunk of 16 is loaded as ONE float4 per lane and operand (lane group j takes k = 16 t + 4 j .. + 3)
+// and consumed by four MFMAs (MFMA e uses component e: the same k permutation on both operands, so the sum is the plain dot
+// product).  U chunks are loaded before the first MFMA: 2 U (3 U with xact) independent 16-byte loads in flight per lane.
+__global__ __launch_bounds__(256) void lin_fwd_kernel(const LinArgs a) {
+  constexpr int U = 8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, j = lane >> 4;
+  const int nb = blockIdx.x * 16, mb = blockIdx.y * 64 + wave * 16, z = blockIdx.z;
+  if (mb >= a.M) return;                                   // (wave-uniform)
+  const int k0 = z * a.k_per_split, k1 = k0 + a.k_per_split < a.Kr ? k0 + a.k_per_split : a.Kr;
+  const int m = mb + i, n = nb + i;
+  const bool mok = m < a.M, nok = n < a.N;
+  const float* xr = a.x + (size_t)(mok ? m : 0) * a.x_pitch;
+  const float* ar = a.xact ? a.xact + (size_t)(mok ? m : 0) * a.xact_pitch : nullptr;
+  const float* wr = a.w + (size_t)(nok ? n : 0) * a.w_row;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int kc = k0; kc < k1; kc += 16 * U) {
+    f32x4 xv[U], wv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = kc + 16 * u + 4 * j;                   // Kr, k_per_split and the pitches are multiples of 4: a float4 is in or out
+      xv[u] = (mok && k < k1) ? *(const f32x4*)(xr + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      wv[u] = (nok && k < k1) ? *(const f32x4*)(wr + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (ar && mok && k < k1) {
+        const f32x4 yv = *(const f32x4*)(ar + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[u][e] *= lin_actgrad(yv[e], a.in_act, a.slope);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][e], wv[u][e], acc, 0, 0, 0);
+  }
+  if (n >= a.n_store) return;
+  const float b = (a.bias && nok && a.ksplit <= 1) ? a.bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int mo = mb + 4 * j + r;
+    if (mo >= a.M) continue;
+    if (a.ksplit > 1) { a.part[((size_t)z * a.M + mo) * a.n_store + n] = acc[r]; continue; }   // partial tile -> workspace [z][M][n_store]
+    float v = nok ? acc[r] + b : 0.f;
+    v = a.act == S2P_ACT_LRELU ? (v > 0.f ? v : v * a.slope) : (a.act == S2P_ACT_RELU ? (v > 0.f ? v : 0.f) : v);
+    a.y[(size_t)mo * a.y_pitch + n] = v;
+  }
+}
+
+// y[m][n] = sum over the K splits, in split order
+__global__ __launch_bounds__(256) void lin_splitk_reduce_kernel(const LinArgs a) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)a.M * a.n_store) return;
+  const int m = (int)(i / a.n_store), n = (int)(i - (long long)m * a.n_store);
+  float s = 0.f;
+  for (int z = 0; z < a.ksplit; ++z) s += a.part[((size_t)z * a.M + m) * a.n_store + n];
+  a.y[(size_t)m * a.y_pitch + n] = s;
+}
+
+// dW[N][K] += dpre^T x, db[N] += sum_m dpre   (dpre = dy * act'(y)).  D[n][k] = sum_m A[n][m] B[m][k]: per MFMA (4 batch rows)
+// a lane loads ONE dpre value and ONE x value (16 lanes = 64 contiguous bytes of a row); the bias gradient is a second MFMA
+// against a column of ones (no cross-lane reduction).  All of a 64-row batch's loads are in flight before the first MFMA.
+__global__ __launch_bounds__(256) void lin_wgrad_kernel(const LinArgs a) {
+  constexpr int U = 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, j = lane >> 4;
+  const int kt_n = (a.K + 63) / 64;
+  const int nb = (blockIdx.x / kt_n) * 16, kb = (blockIdx.x % kt_n) * 64 + wave * 16;
+  if (kb >= a.K) return;                                   // (wave-uniform)
+  const int n = nb + i, k = kb + i;
+  const bool nok = n < a.N, kok = k < a.K;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
+  const bool want_b = a.db && kb == 0;
+  for (int m0 = 0; m0 < a.M; m0 += 4 * U) {
+    float dv[U], xv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int m = m0 + 4 * u + j;
+      const bool mok = m < a.M;
+      dv[u] = (mok && nok) ? a.dy[(size_t)m * a.dy_pitch + n] : 0.f;
+      if (a.yact && mok && nok) dv[u] *= lin_actgrad(a.yact[(size_t)m * a.yact_pitch + n], a.act, a.slope);
+      xv[u] = (mok && kok) ? a.xin[(size_t)m * a.xin_pitch + k] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[u], xv[u], acc, 0, 0, 0);
+      if (want_b) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[u], 1.f, accb, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int no = nb + 4 * j + r;
+    if (no >= a.N) continue;
+    if (k < a.k_real) a.dw[(size_t)no * a.dw_row + k] += acc[r];
+    if (want_b && i == 0) a.db[no] += accb[r];
+  }
+}
+
+#ifdef S2P_DIAG_BUILD
+// ---- diagnostics build only: the LDS-staged VALU kernels of rounds 2-3 (S2P_LIN_LDS=1 selects them), kept as the subject of the
+// LDS co-residency repro (tools/repro_lds_modes.sh, tests/tools/repro_lds.py) -------------------------------------------------
 // ---- how the staged tiles are read back from LDS --------------------------------------------------------------------
 // The tiles are padded to an odd pitch (65 / 17 floats) so that column reads spread over the banks; a row then starts
 // 0 / 4 / 8 / 12 bytes off 16-byte alignment depending on row % 4.  hipcc merges the unrolled k-loop's neighbouring loads
@@ -40,10 +147,6 @@ struct LinArgs {
 constexpr int LIN_LD = S2P_LIN_LDS_MODE == 2 ? 68 : 65;
 __device__ __forceinline__ float lin_ld_x(const float* p) { return (S2P_LIN_LDS_MODE == 0 || S2P_LIN_LDS_MODE == 4) ? lds_ld(p) : *p; }
 __device__ __forceinline__ float lin_ld_w(const float* p) { return (S2P_LIN_LDS_MODE == 0 || S2P_LIN_LDS_MODE == 3) ? lds_ld(p) : *p; }
-
-__device__ __forceinline__ float lin_actgrad(float yv, int act, float slope) {
-  return act == S2P_ACT_LRELU ? (yv > 0.f ? 1.f : slope) : (act == S2P_ACT_RELU ? (yv > 0.f ? 1.f : 0.f) : 1.f);
-}
 
 // y tile [64 rows][16 cols] of  x'[M][Kr] . W[N][Kr]^T,  x' = x * act'(xact) when xact != nullptr
 __device__ __forceinline__ void lin_gemm_tile(const LinArgs& a, int mb, int nb, int k0, int k1, float (&acc)[4], float* xs, float* ws) {
@@ -99,7 +202,7 @@ __device__ __forceinline__ void lin_gemm_tile(const LinArgs& a, int mb, int nb, 
   }
 }
 
-__global__ __launch_bounds__(256) void lin_fwd_kernel(const LinArgs a) {
+__global__ __launch_bounds__(256) void lin_fwd_lds_kernel(const LinArgs a) {
   __shared__ __attribute__((aligned(16))) float xs[64 * LIN_LD], ws[16 * LIN_LD];
   const int nb = blockIdx.x * 16, mb = blockIdx.y * 64, z = blockIdx.z;
   const int k0 = z * a.k_per_split, k1 = k0 + a.k_per_split < a.Kr ? k0 + a.k_per_split : a.Kr;
@@ -127,18 +230,8 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(const LinArgs a) {
   }
 }
 
-// y[m][n] = sum over the K splits, in split order
-__global__ __launch_bounds__(256) void lin_splitk_reduce_kernel(const LinArgs a) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (long long)a.M * a.n_store) return;
-  const int m = (int)(i / a.n_store), n = (int)(i - (long long)m * a.n_store);
-  float s = 0.f;
-  for (int z = 0; z < a.ksplit; ++z) s += a.part[((size_t)z * a.M + m) * a.n_store + n];
-  a.y[(size_t)m * a.y_pitch + n] = s;
-}
-
 // dW[N][K] += dpre^T x, db[N] += sum_m dpre   (dpre = dy * act'(y))
-__global__ __launch_bounds__(256) void lin_wgrad_kernel(const LinArgs a) {
+__global__ __launch_bounds__(256) void lin_wgrad_lds_kernel(const LinArgs a) {
   constexpr int LDX = LIN_LD, LDD = S2P_LIN_LDS_MODE == 2 ? 20 : 17;   // pitches of the x / dpre tiles (mode 2: 16-byte-aligned rows)
   __shared__ __attribute__((aligned(16))) float xs[64 * LDX], ws[64 * LDD];
   const int t = threadIdx.x;
@@ -195,6 +288,19 @@ __global__ __launch_bounds__(256) void lin_wgrad_kernel(const LinArgs a) {
   }
 }
 
+#endif  // S2P_DIAG_BUILD
+
+#ifdef S2P_DIAG_BUILD
+static inline bool lin_use_lds() { static const int v = s2p_env_set("S2P_LIN_LDS"); return v != 0; }
+#define LIN_LAUNCH_FWD(grid, st, args) do { if (lin_use_lds()) hipLaunchKernelGGL(lin_fwd_lds_kernel, grid, dim3(256), 0, st, args); \
+                                            else hipLaunchKernelGGL(lin_fwd_kernel, grid, dim3(256), 0, st, args); } while (0)
+#define LIN_LAUNCH_WGRAD(grid, st, args) do { if (lin_use_lds()) hipLaunchKernelGGL(lin_wgrad_lds_kernel, grid, dim3(256), 0, st, args); \
+                                              else hipLaunchKernelGGL(lin_wgrad_kernel, grid, dim3(256), 0, st, args); } while (0)
+#else
+#define LIN_LAUNCH_FWD(grid, st, args) hipLaunchKernelGGL(lin_fwd_kernel, grid, dim3(256), 0, st, args)
+#define LIN_LAUNCH_WGRAD(grid, st, args) hipLaunchKernelGGL(lin_wgrad_kernel, grid, dim3(256), 0, st, args)
+#endif
+
 static int lin_check(const char* who, int M, int K, int N, int xp) {
   if (M <= 0 || K <= 0 || N <= 0) S2P_FAIL(-1, "%s: empty problem", who);
   if (K % 4 || xp % 4) S2P_FAIL(-1, "%s: K and pitches must be multiples of 4 floats", who);
@@ -208,7 +314,7 @@ extern "C" int s2p_linear_fwd(const float* x, int M, int K, int x_pitch, const f
   if (!x || !w || !y || w_row % 4 || n_store < N || n_store > y_pitch) S2P_FAIL(-1, "s2p_linear_fwd: bad arguments");
   LinArgs a{}; a.x = x; a.w = w; a.bias = bias; a.y = y; a.M = M; a.Kr = K; a.N = N; a.x_pitch = x_pitch; a.w_row = w_row;
   a.y_pitch = y_pitch; a.n_store = n_store; a.act = act; a.slope = slope; a.ksplit = 1; a.k_per_split = K;
-  hipLaunchKernelGGL(lin_fwd_kernel, dim3(cdiv(n_store, 16), cdiv(M, 64), 1), dim3(256), 0, (hipStream_t)stream, a);
+  LIN_LAUNCH_FWD(dim3(cdiv(n_store, 16), cdiv(M, 64), 1), (hipStream_t)stream, a);
   S2P_CHECK_LAUNCH("lin_fwd_kernel");
   return 0;
 }
@@ -236,7 +342,7 @@ extern "C" int s2p_linear_bwd(const float* x, int x_pitch, const float* dy, int 
   a.xin = x; a.xin_pitch = x_pitch; a.dy = dy; a.dy_pitch = dy_pitch; a.yact = act != S2P_ACT_NONE ? y : nullptr;
   a.yact_pitch = y_pitch; a.dw = dw; a.dw_row = dw_row; a.db = db; a.K = K; a.k_real = k_real; a.N = N;
   const int wg_blocks = cdiv(N, 16) * cdiv(K, 64);
-  hipLaunchKernelGGL(lin_wgrad_kernel, dim3(wg_blocks), dim3(256), 0, st, a);
+  LIN_LAUNCH_WGRAD(dim3(wg_blocks), st, a);
   S2P_CHECK_LAUNCH("lin_wgrad_kernel");
   if (!dx) return 0;
   // dgrad: "x" = dy (with the activation derivative folded in), reduction over N, output columns = the K inputs
@@ -249,7 +355,7 @@ extern "C" int s2p_linear_bwd(const float* x, int x_pitch, const float* dy, int 
   g.N = K;
   if (ks == 1) {
     g.ksplit = 1; g.k_per_split = g.Kr;
-    hipLaunchKernelGGL(lin_fwd_kernel, dim3(cdiv(g.n_store, 16), cdiv(M, 64), 1), dim3(256), 0, st, g);
+    LIN_LAUNCH_FWD(dim3(cdiv(g.n_store, 16), cdiv(M, 64), 1), st, g);
     S2P_CHECK_LAUNCH("lin_fwd_kernel(dgrad)");
     return 0;
   }
@@ -257,7 +363,7 @@ extern "C" int s2p_linear_bwd(const float* x, int x_pitch, const float* dy, int 
   if (!workspace || workspace_bytes < need) S2P_FAIL(-1, "s2p_linear_bwd: workspace of %zu bytes needed", need);
   g.part = (float*)workspace; g.ksplit = ks; g.k_per_split = cdiv(g.Kr, ks); g.k_per_split = (g.k_per_split + 63) / 64 * 64;
   g.ksplit = cdiv(g.Kr, g.k_per_split);
-  hipLaunchKernelGGL(lin_fwd_kernel, dim3(cdiv(g.n_store, 16), cdiv(M, 64), g.ksplit), dim3(256), 0, st, g);
+  LIN_LAUNCH_FWD(dim3(cdiv(g.n_store, 16), cdiv(M, 64), g.ksplit), st, g);
   S2P_CHECK_LAUNCH("lin_fwd_kernel(dgrad, split)");
   hipLaunchKernelGGL(lin_splitk_reduce_kernel, dim3(cdiv((long long)M * g.n_store, 256)), dim3(256), 0, st, g);
   S2P_CHECK_LAUNCH("lin_splitk_reduce_kernel");

@@ -165,8 +165,9 @@ def test_conv_geometry_matches_torch():
 def test_lds_access_widths():
     """ISA-level guard for the LDS co-residency hazard, no GPU needed: disassemble every gfx950 kernel of
     libs2p_hip.so and check which LDS read instructions it contains.
-      * the state path's linear kernels must read LDS with single-dword instructions only (the merged reads hipcc would
-        form on their weight tile are the ones that returned wrong data beside LDS-DMA kernels);
+      * the state path's linear kernels -- the family the hazard was found on (merged multi-dword reads of their LDS weight tile
+        returned wrong data beside LDS-DMA kernels) -- must contain NO LDS instruction at all: they feed the fp32 MFMAs straight
+        from global memory (csrc/linear_small.hip), which puts them outside the hazard class by construction;
       * every OTHER kernel that has multi-dword LDS reads and does not itself stage through LDS-DMA must be on the list below,
         i.e. must have been run as a victim in tests/test_model_gpu.py::test_small_kernels_are_undisturbed_by_lds_dma_kernels...
         -- a new kernel, or a compiler / code change that starts merging LDS reads in a kernel that is not listed, fails here
@@ -185,8 +186,7 @@ def test_lds_access_widths():
     lin = [k for k in a if re.search(r"lin_(fwd|wgrad)_kernel", names[k])]
     assert len(lin) == 2, [names[k] for k in lin]
     for k in lin:
-        assert not wide_reads(a[k]), (names[k], dict(a[k]["ds"]))
-        assert a[k]["ds"].get("ds_read_b32", 0) >= 40
+        assert not a[k]["ds"] and not a[k]["lds_dma"], (names[k], dict(a[k]["ds"]))
     # non-DMA kernels that are allowed to contain multi-dword LDS reads: each is a victim of the GPU co-residency test
     verified = [r"in_(reduce|apply|fused_fwd|fused_bwd)_kernel", r"thin_(fwd|cin_fwd|rows_fwd|tiled_fwd|tiled_wgrad)_kernel",
                 r"head_(fwd|wgrad|wgrad_reduce)_kernel", r"conv_part_reduce_kernel", r"wgrad_part_reduce_kernel",
