@@ -36,8 +36,11 @@ __device__ __forceinline__ float lin_actgrad(float yv, int act, float slope) {
 // D[row 4 j + r][col i].  A k-chunk of 16 is loaded as ONE float4 per lane and operand (lane group j takes k = 16 t + 4 j .. + 3)
 // and consumed by four MFMAs (MFMA e uses component e: the same k permutation on both operands, so the sum is the plain dot
 // product).  U chunks are loaded before the first MFMA: 2 U (3 U with xact) independent 16-byte loads in flight per lane.
+#ifndef S2P_LIN_U
+#define S2P_LIN_U 8
+#endif
 __global__ __launch_bounds__(256) void lin_fwd_kernel(const LinArgs a) {
-  constexpr int U = 8;
+  constexpr int U = S2P_LIN_U;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, j = lane >> 4;
   const int nb = blockIdx.x * 16, mb = blockIdx.y * 64 + wave * 16, z = blockIdx.z;
   if (mb >= a.M) return;                                   // (wave-uniform)
