@@ -533,59 +533,82 @@ extern "C" int s2p_adam_step_dev(float* p, const float* g, float* m, float* v, i
 // ---- weight packing: fp32 channels-last master [R][T][C] -> compute dtype, both GEMM orientations ----------
 // fwd: dst_fwd[r][t][c] (row length T*Cpad, zeros for c >= C);  bwd: dst_bwd[c][t][r_off + r] (row length
 // T*Rrow; rows c >= C and columns outside [r_off, r_off+R) are never written: the caller pre-zeroes them once).
+// One pass over the master: per tap t, a 64 x 64 (r x c) tile is read ONCE with 16-byte loads along c (the master's contiguous
+// axis); the forward operand goes out from the registers (8-byte bf16 stores along c), the transposed backward operand through a
+// 64 x 65 LDS tile (8-byte stores along r).  (Rounds 1-2 read the master twice, the second time through 32 x 32 tiles with two
+// barriers per 1024 elements: 69 + 58 us per step for G + D.)
 template <typename T>
-__device__ void pack_one(const s2p_pack_job& j, int part, int nparts, float (*tile)[33]) {
+__device__ void pack_one(const s2p_pack_job& j, int part, int nparts, float (*tile)[65]) {
   const int tid = threadIdx.x;
-  if (j.dst_fwd) {
-    T* d = (T*)j.dst_fwd;
-    if (j.Cpad == j.C && (j.C & 3) == 0) {
-      // straight cast copy, 4 elements per thread
-      const long long tot4 = (long long)j.R * j.T * j.C / 4;
-      for (long long i = (long long)part * 256 + tid; i < tot4; i += (long long)nparts * 256) {
-        const f32x4 v = *(const f32x4*)(j.src + 4 * i);
+  T* df = (T*)j.dst_fwd;
+  T* db = (T*)j.dst_bwd;
+  const int Cw = df ? (j.Cpad > j.C ? j.Cpad : j.C) : j.C;       // columns to cover (the forward operand's zero padding included)
+  const int tr = (j.R + 63) / 64, tc = (Cw + 63) / 64;
+  const long long ntiles = (long long)tr * tc * j.T;
+  const int rr = tid >> 4, cq = tid & 15;                    // 16 rows x 16 four-column chunks per pass, 4 passes
+  const bool vec_src = (j.C & 3) == 0;                       // master rows start 16-byte aligned and hold whole float4s
+  const bool vec_bwd = db && (j.Rrow & 3) == 0 && (j.r_off & 3) == 0;
+  for (long long q = part; q < ntiles; q += nparts) {
+    const int t = (int)(q % j.T); const long long rc = q / j.T;
+    const int r0 = (int)(rc % tr) * 64, c0 = (int)(rc / tr) * 64;
+    if (db) __syncthreads();                                 // previous tile's transposed reads are done
 #pragma unroll
-        for (int e = 0; e < 4; ++e) d[4 * i + e] = from_f32<T>(v[e]);
+    for (int k = 0; k < 4; ++k) {
+      const int r = r0 + rr + 16 * k, c = c0 + 4 * cq;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < j.R && c < j.C) {
+        const float* sp = j.src + ((long long)r * j.T + t) * j.C + c;
+        if (vec_src) v = *(const f32x4*)sp;
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (c + e < j.C) v[e] = sp[e];
+        }
       }
-    } else {
-      const long long tot = (long long)j.R * j.T * j.Cpad;
-      for (long long i = (long long)part * 256 + tid; i < tot; i += (long long)nparts * 256) {
-        int c = (int)(i % j.Cpad); long long rt = i / j.Cpad;
-        d[i] = from_f32<T>(c < j.C ? j.src[rt * j.C + c] : 0.f);
+      if (df && r < j.R && c < j.Cpad) {                     // Cpad is a multiple of the 16-byte chunk: c + 3 < Cpad
+        T* dp = df + ((long long)r * j.T + t) * j.Cpad + c;
+        if constexpr (sizeof(T) == 2) {
+          typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+          *(bf16x4_t*)dp = (bf16x4_t){(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        } else {
+          *(f32x4*)dp = v;
+        }
+      }
+      if (db) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[rr + 16 * k][4 * cq + e] = v[e];
       }
     }
-  }
-  if (j.dst_bwd) {
-    // per tap t: transpose the R x C matrix through a 32 x 32 LDS tile (coalesced fp32 reads along c, contiguous
-    // compute-dtype writes along r)
-    T* d = (T*)j.dst_bwd;
-    const int tr = (j.R + 31) / 32, tc = (j.C + 31) / 32;
-    const long long ntiles = (long long)tr * tc * j.T;
-    const int tx = tid & 31, ty = tid >> 5;              // 32 x 8
-    for (long long q = part; q < ntiles; q += nparts) {
-      const int t = (int)(q % j.T); const long long rc = q / j.T;
-      const int r0 = (int)(rc % tr) * 32, c0 = (int)(rc / tr) * 32;
-      __syncthreads();
+    if (!db) continue;
+    __syncthreads();
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int r = r0 + ty + 8 * k, c = c0 + tx;
-        tile[ty + 8 * k][tx] = (r < j.R && c < j.C) ? j.src[((long long)r * j.T + t) * j.C + c] : 0.f;
-      }
-      __syncthreads();
+    for (int k = 0; k < 4; ++k) {
+      const int c = c0 + rr + 16 * k, r = r0 + 4 * cq;       // output row c, four consecutive r
+      if (c >= j.C || r >= j.R) continue;
+      T* dp = db + ((long long)c * j.T + t) * j.Rrow + j.r_off + r;
+      float w[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int c = c0 + ty + 8 * k, r = r0 + tx;
-        if (c < j.C && r < j.R) d[((long long)c * j.T + t) * j.Rrow + j.r_off + r] = from_f32<T>(tile[tx][ty + 8 * k]);
+      for (int e = 0; e < 4; ++e) w[e] = tile[4 * cq + e][rr + 16 * k];
+      if (vec_bwd && r + 3 < j.R) {
+        if constexpr (sizeof(T) == 2) {
+          typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+          *(bf16x4_t*)dp = (bf16x4_t){(__bf16)w[0], (__bf16)w[1], (__bf16)w[2], (__bf16)w[3]};
+        } else {
+          *(f32x4*)dp = (f32x4){w[0], w[1], w[2], w[3]};
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (r + e < j.R) dp[e] = from_f32<T>(w[e]);
       }
     }
   }
 }
 __global__ __launch_bounds__(256) void pack_kernel(const s2p_pack_job* jobs) {
-  __shared__ float tile[32][33];
+  __shared__ float tile[64][65];
   const s2p_pack_job j = jobs[blockIdx.y];
-  // the grid is sized for the largest job (2048 elements per workgroup); a smaller job uses only as many workgroups as it
-  // has 2048-element parts and the rest return at once (the jobs of one network differ by 4 orders of magnitude in size)
-  const long long el = (long long)j.R * j.T * (j.Cpad > j.C ? j.Cpad : j.C);
-  long long need = (el + 2047) / 2048;
+  // the grid is sized for the largest job (one 64 x 64 tile per workgroup and pass); a smaller job uses only as many workgroups as
+  // it has tiles and the rest return at once (the jobs of one network differ by 4 orders of magnitude in size)
+  const int Cw = j.dst_fwd ? (j.Cpad > j.C ? j.Cpad : j.C) : j.C;
+  long long need = (long long)((j.R + 63) / 64) * ((Cw + 63) / 64) * j.T;
   if (need > (long long)gridDim.x) need = gridDim.x;
   if (need < 1) need = 1;
   if ((long long)blockIdx.x >= need) return;
@@ -594,7 +617,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const s2p_pack_job* jobs) {
 }
 extern "C" int s2p_pack_weights(const s2p_pack_job* jobs, int n_jobs, int max_elems, void* stream) {
   if (!jobs || n_jobs <= 0) S2P_FAIL(-1, "s2p_pack_weights: bad argument");
-  int parts = (max_elems + 256 * 8 - 1) / (256 * 8); if (parts < 1) parts = 1; if (parts > 2048) parts = 2048;
+  int parts = (max_elems + 4095) / 4096; if (parts < 1) parts = 1; if (parts > 2048) parts = 2048;     // ~ one 64 x 64 tile per workgroup
   hipLaunchKernelGGL(pack_kernel, dim3(parts, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs);
   S2P_CHECK_LAUNCH("pack_kernel");
   return 0;

@@ -812,3 +812,41 @@ def test_conv_plane_kernels_epilogues_and_groups(hip_device, N, HW_):
     refw = torch.cat([torch.autograd.grad(F.conv2d(xg[:, i * ci:(i + 1) * ci].double(), wv, padding=1), wv, dyg[:, i * co:(i + 1) * co].double())[0]
                       for i in range(G) for wv in [wg[i * co:(i + 1) * co].double().requires_grad_(True)]])
     assert rel_err(dw_b.view(G * co, 3, 3, ci).permute(0, 3, 1, 2).cpu(), refw) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_pack_weights_against_torch(hip_device, dtype):
+    """s2p_pack_weights (csrc/misc.hip): fp32 channels-last master [R][T][C] -> the forward operand [R][T][Cpad] (zero pad) and the
+    transposed backward operand [C][T][Rrow] at column offset r_off, in the compute dtype: bitwise against torch's cast, over
+    ragged shapes (C not a multiple of 4, R not a multiple of the tile, one-tap linear layers, a fused two-member matrix) in ONE
+    launch; elements the jobs do not own keep their previous contents."""
+    import ctypes
+    from s2p_amd import _lib
+    dev = hip_device
+    g = torch.Generator().manual_seed(5)
+    ce = _lib.chunk_elems(dtype)
+    shapes = [(64, 9, 64, 0, 64), (100, 9, 3, 0, 100), (70, 16, 6, 0, 70), (256, 1, 357, 0, 256), (33, 49, 17, 0, 33),
+              (128, 9, 128, 0, 256), (128, 9, 128, 128, 256), (1, 16, 512, 0, 1), (130, 4, 260, 2, 136)]     # R, T, C, r_off, Rrow(min)
+    jobs, keep = [], []
+    for (R, T, C, r_off, rrow) in shapes:
+        Cpad, Rrow = ops.pad_to(C, ce), ops.pad_to(max(rrow, r_off + R), ce)
+        src = torch.randn(R, T, C, generator=g).to(dev)
+        fwd = torch.full((R, T, Cpad), 7.0, dtype=dtype, device=dev)
+        bwd = torch.full((C, T, Rrow), 7.0, dtype=dtype, device=dev)
+        jobs.append(_lib.PackJob(src.data_ptr(), fwd.data_ptr(), bwd.data_ptr(), R, T, C, Cpad, Rrow, r_off, _lib.dtype_id(dtype)))
+        keep.append((src, fwd, bwd, R, T, C, Cpad, Rrow, r_off))
+    # a forward-only job (need_bwd=False packs)
+    srcf = torch.randn(48, 9, 8, generator=g).to(dev); fwdf = torch.full((48, 9, 8), 7.0, dtype=dtype, device=dev)
+    jobs.append(_lib.PackJob(srcf.data_ptr(), fwdf.data_ptr(), 0, 48, 9, 8, 8, 48, 0, _lib.dtype_id(dtype)))
+    arr = (_lib.PackJob * len(jobs))(*jobs)
+    jd = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    mx = max(s.numel() for s, *_ in keep)
+    for _ in range(2):
+        _lib.check(_lib.lib().s2p_pack_weights(_lib.ptr(jd), len(jobs), mx, _lib.stream()), "s2p_pack_weights")
+    torch.cuda.synchronize()
+    for (src, fwd, bwd, R, T, C, Cpad, Rrow, r_off) in keep:
+        ref_f = torch.zeros(R, T, Cpad, dtype=dtype, device=dev); ref_f[:, :, :C] = src.to(dtype)
+        assert torch.equal(fwd, ref_f), (R, T, C)
+        ref_b = torch.full((C, T, Rrow), 7.0, dtype=dtype, device=dev); ref_b[:, :, r_off:r_off + R] = src.permute(2, 1, 0).to(dtype)
+        assert torch.equal(bwd, ref_b), (R, T, C, r_off)
+    assert torch.equal(fwdf, srcf.to(dtype))
