@@ -346,26 +346,43 @@ extern "C" int s2p_l1_loss(int dtype, const void* a, const void* b, int64_t coun
 }
 // several L1 terms in ONE launch (the 8 feature-matching maps of the two PatchGAN scales, the 5 VGG taps): blockIdx.y = job.
 // Every job needs 16-byte aligned pointers and a count that is a multiple of the chunk (NHWC activations are both).
+// The jobs differ by up to 35x in size (VGG relu1_1 .. relu5_1): each gets workgroups in proportion to its size (first[j] =
+// its first workgroup of the 1-D grid), and a thread keeps four chunk pairs in flight.
 struct L1Multi { const void* a[S2P_L1_MAX_JOBS]; const void* b[S2P_L1_MAX_JOBS]; void* g[S2P_L1_MAX_JOBS];
-                 long long count[S2P_L1_MAX_JOBS]; float scale[S2P_L1_MAX_JOBS]; float* loss[S2P_L1_MAX_JOBS]; };
+                 long long count[S2P_L1_MAX_JOBS]; float scale[S2P_L1_MAX_JOBS]; float* loss[S2P_L1_MAX_JOBS];
+                 int first[S2P_L1_MAX_JOBS + 1]; int n_jobs; };
 template <typename T>
-__global__ void l1_multi_kernel(const L1Multi m) {
+__global__ __launch_bounds__(256) void l1_multi_kernel(const L1Multi m) {
   constexpr int CE = DT<T>::CE;
-  const int j = blockIdx.y;
+  int j = 0;
+  while (j + 1 < m.n_jobs && (int)blockIdx.x >= m.first[j + 1]) ++j;
+  const int blk = blockIdx.x - m.first[j], nblk = m.first[j + 1] - m.first[j];
   const T* a = (const T*)m.a[j]; const T* b = (const T*)m.b[j]; T* grad = (T*)m.g[j];
   const long long nch = m.count[j] / CE;
   const float scale = m.scale[j];
+  const long long stride = (long long)nblk * 256;
   float s = 0.f;
-  GRID_STRIDE(ci, nch) {
-    Chunk<T> av, bv, gv;
-    av.raw = *(const u32x4*)(a + ci * CE); bv.raw = *(const u32x4*)(b + ci * CE);
+  for (long long c0 = (long long)blk * 256 + threadIdx.x; c0 < nch; c0 += 4 * stride) {
+    Chunk<T> av[4], bv[4];
 #pragma unroll
-    for (int e = 0; e < CE; ++e) {
-      const float d = av.get(e) - bv.get(e);
-      s += fabsf(d);
-      gv.set(e, d > 0.f ? scale : (d < 0.f ? -scale : 0.f));
+    for (int u = 0; u < 4; ++u) {
+      const long long ci = c0 + u * stride;
+      av[u].raw = (u32x4){0u, 0u, 0u, 0u}; bv[u].raw = av[u].raw;
+      if (ci < nch) { av[u].raw = *(const u32x4*)(a + ci * CE); bv[u].raw = *(const u32x4*)(b + ci * CE); }
     }
-    if (grad) *(u32x4*)(grad + ci * CE) = gv.raw;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long ci = c0 + u * stride;
+      if (ci >= nch) break;
+      Chunk<T> gv;
+#pragma unroll
+      for (int e = 0; e < CE; ++e) {
+        const float d = av[u].get(e) - bv[u].get(e);
+        s += fabsf(d);
+        gv.set(e, d > 0.f ? scale : (d < 0.f ? -scale : 0.f));
+      }
+      if (grad) *(u32x4*)(grad + ci * CE) = gv.raw;
+    }
   }
   block_atomic_add(s * scale, m.loss[j]);
 }
@@ -373,17 +390,19 @@ extern "C" int s2p_l1_loss_multi(int dtype, const s2p_l1_job* jobs, int n_jobs, 
   if (!jobs || n_jobs < 1 || n_jobs > S2P_L1_MAX_JOBS) S2P_FAIL(-1, "s2p_l1_loss_multi: 1..%d jobs", S2P_L1_MAX_JOBS);
   const int ce = dtype == S2P_F32 ? 4 : 8;
   L1Multi m{};
-  long long maxc = 0;
+  m.n_jobs = n_jobs;
   for (int j = 0; j < n_jobs; ++j) {
     const s2p_l1_job& q = jobs[j];
     if (!q.a || !q.b || !q.loss_out || q.count <= 0) S2P_FAIL(-1, "s2p_l1_loss_multi: job %d: null pointer / empty", j);
     if (((unsigned long long)q.a | (unsigned long long)q.b | (unsigned long long)q.grad_a) & 15ull || q.count % ce)
       S2P_FAIL(-1, "s2p_l1_loss_multi: job %d: pointers must be 16-byte aligned and count a multiple of %d", j, ce);
     m.a[j] = q.a; m.b[j] = q.b; m.g[j] = q.grad_a; m.count[j] = q.count; m.scale[j] = q.scale; m.loss[j] = q.loss_out;
-    if (q.count > maxc) maxc = q.count;
+    // one workgroup per 256 threads x 4 chunks x 4 rounds; same-address atomics retire at ~13 ns each: <= 512 workgroups per job
+    static const int cap = s2p_env_int("S2P_L1_BLOCKS", 512);
+    long long nb = (q.count / ce + 4095) / 4096; if (nb > cap) nb = cap; if (nb < 1) nb = 1;
+    m.first[j + 1] = m.first[j] + (int)nb;
   }
-  // same-address atomics retire at ~13 ns each: <= 128 workgroups per job
-  dim3 g(grid_for(maxc / ce / 4, 128), n_jobs);
+  dim3 g(m.first[n_jobs]);
   if (dtype == S2P_F32) hipLaunchKernelGGL(l1_multi_kernel<float>, g, dim3(256), 0, (hipStream_t)stream, m);
   else if (dtype == S2P_BF16) hipLaunchKernelGGL(l1_multi_kernel<__bf16>, g, dim3(256), 0, (hipStream_t)stream, m);
   else S2P_FAIL(-1, "s2p_l1_loss_multi: bad dtype");

@@ -17,3 +17,12 @@ for shape in [(64, 84, 84, 64), (64, 42, 42, 128), (64, 21, 21, 256), (64, 10, 1
     a = torch.randn(*shape, device=dev).bfloat16(); b = torch.randn(*shape, device=dev).bfloat16(); g = torch.empty_like(a)
     t = timeit(lambda: ops.l1_loss(a, b, 1.0 / a.numel(), loss, g))
     print("%-22s %7.1f us  %5.2f TB/s" % (shape, t, a.numel() * 6 / t / 1e6), flush=True)
+# the five VGG taps in ONE launch (s2p_l1_loss_multi), as the perceptual loss calls it
+shapes = [(64, 84, 84, 64), (64, 42, 42, 128), (64, 21, 21, 256), (64, 10, 10, 512), (64, 5, 5, 512)]
+A = [torch.randn(*s, device=dev).bfloat16() for s in shapes]; B = [torch.randn(*s, device=dev).bfloat16() for s in shapes]
+G = [torch.empty_like(a) for a in A]
+lm = torch.zeros(5, device=dev)
+jobs = [(A[i], B[i], 1.0 / A[i].numel(), lm[i:i + 1], G[i]) for i in range(5)]
+t = timeit(lambda: ops.l1_loss_multi(jobs))
+tot = sum(a.numel() for a in A) * 6
+print("five VGG taps, one launch: %7.1f us  %5.2f TB/s" % (t, tot / t / 1e6))
