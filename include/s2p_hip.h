@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define S2P_VERSION 113
+#define S2P_VERSION 114
 
 enum { S2P_F32 = 0, S2P_BF16 = 1 };
 enum { S2P_ACT_NONE = 0, S2P_ACT_RELU = 1, S2P_ACT_LRELU = 2, S2P_ACT_TANH = 3, S2P_ACT_SWISH = 4 };

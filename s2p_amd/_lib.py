@@ -136,7 +136,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the export is missing
             fn.argtypes = args
             fn.restype = _RESTYPE.get(name, c_int)
-        if L.s2p_version() < 113:
+        if L.s2p_version() < 114:
             raise RuntimeError("libs2p_hip.so is older than this package")
         _lib = L
     return _lib
