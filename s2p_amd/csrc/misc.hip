@@ -606,7 +606,7 @@ __device__ void pack_one(const s2p_pack_job& j, int part, int nparts, float (*ti
       T* dp = db + ((long long)c * j.T + t) * j.Rrow + j.r_off + r;
       float w[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) w[e] = tile[4 * cq + e][rr + 16 * k];
+      for (int e = 0; e < 4; ++e) w[e] = lds_ld(&tile[4 * cq + e][rr + 16 * k]);   // single-dword reads of the odd-pitch tile
       if (vec_bwd && r + 3 < j.R) {
         if constexpr (sizeof(T) == 2) {
           typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
