@@ -26,7 +26,7 @@ def timeit(fn, n=K):
 tf_ = tb_ = 0.0
 for (N, H, W, ci, co, k, s, p) in [(64, 43, 43, 64, 128, 4, 2, 2), (64, 22, 22, 128, 256, 4, 2, 2), (64, 12, 12, 256, 512, 4, 1, 2),
                                    (64, 22, 22, 64, 128, 4, 2, 2), (64, 12, 12, 128, 256, 4, 2, 2), (64, 7, 7, 256, 512, 4, 1, 2),
-                                   (64, 10, 10, 512, 512, 3, 1, 1), (64, 5, 5, 512, 512, 3, 1, 1)]:
+                                   (64, 10, 10, 512, 512, 3, 1, 1), (64, 5, 5, 512, 512, 3, 1, 1), (64, 84, 84, 64, 64, 3, 1, 1)]:
     geom = ops.ConvGeom(ci, co, k, s, p)
     Ho, Wo = geom.out_hw(H, W)
     xs = [torch.randn(N, H, W, ci, device=dev).to(dt) for _ in range(K)]
