@@ -69,6 +69,15 @@ def chain_n():
     return x
 
 
+def chain_n_rev():
+    """N consumed in the REVERSE of the production order (the planes written last are read first)"""
+    ops.conv_fwd(g12n, actv, w12, b12, NH, y_pitch=2 * C, out=gbn)
+    x = x0
+    for k in range(NN - 1, 0, -1):
+        _, x, _ = ops.conv_fwd_mat(geom, x, wf[k], b, C, gbn[k], 0, st, k * 2 * C, ACT_LRELU, 0.2)
+    return x
+
+
 def only_gb12n(): ops.conv_fwd(g12n, actv, w12, b12, NH, y_pitch=2 * C, out=gbn)
 
 
@@ -86,4 +95,6 @@ yn = chain_n()
 print("norm-major chain agrees:", float((ya.float() - yn.float()).abs().max()))
 tn, t12n = timeit(chain_n), timeit(only_gb12n)
 print("N (norm-major planes) %.1f us | its 12-group conv %.1f us | fused convs %.1f us each" % (tn, t12n, (tn - t12n) / 11))
+tnr = timeit(chain_n_rev)
+print("N consumed newest-first: %.1f us | fused convs %.1f us each" % (tnr, (tnr - t12n) / 11))
 print("fused convs in A: %.1f us each | in B: %.1f us each" % ((ta - t12) / 11, (tb - t1) / 11))
