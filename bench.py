@@ -307,6 +307,18 @@ def main():
         dominant = dict(kind=dk, shape_N_H_W_Cin_Cout_k_stride_groups_transposed=list(dshape), launches_per_step=dv[2],
                         avg_launch_us=round(dv[1] * 1e3 / dv[2], 2), gflop_per_launch=round(dv[0] / dv[2] / 1e9, 2),
                         tflops=round(dv[0] / (dv[1] * 1e-3) / 1e12, 2), frac=round(dv[0] / (dv[1] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4))
+        # dominant KERNEL: the launch group (kind, shape, variant) with the largest time per step -- a shape runs as several
+        # kernels (plain conv / + fused MAT-norm forward / + fused norm backward), each with its own duration and HBM bytes
+        vgroups = {}
+        for r in recs:
+            vk = vgroups.setdefault((r["kind"], r["shape"], r.get("variant", "plain")), [0.0, 0.0, 0, 0.0])
+            vk[0] += r["flops"]; vk[1] += r["ms"]; vk[2] += 1; vk[3] += r.get("norm_bytes", 0.0)
+        (vkind, vshape, vvar), vv = max(vgroups.items(), key=lambda kv: kv[1][1])
+        dominant_kernel = dict(kind=vkind, variant=vvar, shape_N_H_W_Cin_Cout_k_stride_groups_transposed=list(vshape),
+                               launches_per_step=vv[2], us_per_step=round(vv[1] * 1e3, 1), avg_launch_us=round(vv[1] * 1e3 / vv[2], 2),
+                               gflop_per_launch=round(vv[0] / vv[2] / 1e9, 2), tflops=round(vv[0] / (vv[1] * 1e-3) / 1e12, 2),
+                               frac=round(vv[0] / (vv[1] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                               fused_norm_mb_per_launch=round(vv[3] / vv[2] / 1e6, 2))
         # the dominant launch alone and SUSTAINED: 20 launches of the ResBlk conv captured in one hipGraph, replayed 5 times between
         # two HIP events (no host launch gap; back-to-back MFMA load, so the chip runs at its sustained MFMA clock: slower than
         # the same launch between the HBM-bound norm kernels of the real step, which is what rocprofv3's per-dispatch time shows)
@@ -351,11 +363,20 @@ def main():
                 if meta.get("s2p_version") != _l.lib().s2p_version():
                     raise RuntimeError("%s was measured on library version %s, this run loads %s: not reported" % (
                         os.path.basename(cands[-1]), meta.get("s2p_version"), _l.lib().s2p_version()))
+                # the counters of the kernel variant that dominates the dominant shape in THIS run's instrumented step
+                # (template argument MAT: 0 plain conv, 1 + fused norm forward, 2 + fused norm backward)
+                hq = args.size // 4
+                same_shape = {v: g_ for (k_, sh, v), g_ in vgroups.items() if sh == dshape and k_ in ("fwd", "dgrad")}
+                tvar = max(same_shape, key=lambda v: same_shape[v][1]) if same_shape else "plain"
+                mat = {"plain": 0, "mat_fwd": 1, "mat_bwd": 2}[tvar]
+                tensor_mb = args.batch * hq * hq * 256 * 2 / 1e6
+                alg_mb = {0: 2 * tensor_mb, 1: 5 * tensor_mb, 2: 8 * tensor_mb}[mat] + 256 * 2304 * 2 / 1e6
                 for k, v in tj.items():
-                    if k.startswith("conv_plane_kernel<7, 22, 0, 0>") and ("grid %s " % want_grid) in k and "hbm_read_bytes" in v:
+                    if k.startswith("conv_plane_kernel<7, 22, 0, %d>" % mat) and ("grid %s " % want_grid) in k and "hbm_read_bytes" in v:
                         traffic = int(v["hbm_read_bytes"] + v["hbm_write_bytes"])          # HBM bytes per launch of the dominant kernel
-                        traffic_detail = dict(hbm_read_mb=round(v["hbm_read_bytes"] / 1e6, 2), hbm_write_mb=round(v["hbm_write_bytes"] / 1e6, 2),
-                                       algorithmic_mb=round((args.batch * (args.size // 4) ** 2 * 256 * 2 * 2 + 256 * 2304 * 2) / 1e6, 2),
+                        traffic_detail = dict(variant=tvar, hbm_read_mb=round(v["hbm_read_bytes"] / 1e6, 2), hbm_write_mb=round(v["hbm_write_bytes"] / 1e6, 2),
+                                       algorithmic_mb=round(alg_mb, 2),
+                                       algorithmic_is="x + y (+ gamma, beta, modulated y | + xn, gamma, beta, res, dxn, dgamma, dbeta) + weights",
                                        mfma_busy_share=round(v.get("mfma_util", 0.0), 4), launches_profiled=v.get("launches"),
                                        source=os.path.relpath(cands[-1], ROOT) + " :: " + k, commit=meta.get("commit"),
                                        s2p_version=meta.get("s2p_version"))
@@ -366,8 +387,9 @@ def main():
                                                "launch, median of the three samples per launch): kernel-alone durations; rocprofv3 counterpart: bench.py --serial-streams",
                         kernel="conv family: conv_plane / conv_halo / conv_dma / conv_gather (fwd, dgrad, incl. fused norm tails) + wgrad_slab / "
                                              "wgrad_dma / wgrad + thin kernels, all %d launches of one step" % len(recs),
-                        dominant_layer=dominant, spade_resblk_fwd_bwd=resblk,
+                        dominant_layer=dominant, dominant_kernel=dominant_kernel, spade_resblk_fwd_bwd=resblk,
                         achieved=round(ach, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                        frac_is="algorithmic_gflop_per_step / conv_ms_per_step (serial-stream sum of the conv family's kernel time) / peak",
                         traffic=traffic, traffic_detail=traffic_detail, algorithmic_gflop_per_step=round(tot_f / 1e9, 1), conv_ms_per_step=round(tot_ms, 3),
                         avg_launch_us=round(tot_ms * 1e3 / max(len(recs), 1), 2),
                         by_kind={k: dict(gflop=round(v[0] / 1e9, 1), ms=round(v[1], 3), launches=v[2],
@@ -380,6 +402,8 @@ def main():
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
+        if roofline is not None:      # the whole overlapped step against the MFMA peak (neither the dominant kernel nor the serial family sum)
+            roofline["step_frac"] = round(roofline["algorithmic_gflop_per_step"] / ms / MFMA_BF16_PEAK_TFLOPS, 4)
         out = {
             "metric": "G+D train-step images/sec at 84x84 bs=64/GPU",
             "value": round(args.batch * world * args.steps / elapsed, 2),

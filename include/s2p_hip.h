@@ -26,8 +26,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: only the entry points declared here are exported */
+#pragma GCC visibility push(default)
 
-#define S2P_VERSION 114
+#define S2P_VERSION 115
 
 enum { S2P_F32 = 0, S2P_BF16 = 1 };
 enum { S2P_ACT_NONE = 0, S2P_ACT_RELU = 1, S2P_ACT_LRELU = 2, S2P_ACT_TANH = 3, S2P_ACT_SWISH = 4 };
@@ -94,8 +96,10 @@ int s2p_conv2d_dgrad_ws(const s2p_conv_desc* d, const void* dy, const void* w_bw
  *   y      = conv(x, w) + bias  [+ aux with epi == S2P_EPI_ADD]                 (kept: the backward needs it)
  *   y_mat  = act(IN(y) * (1 + g_img + g_st) + b_img + b_st),  stats = the statistics of y (s2p_in_stats format)
  * For bf16 3x3 stride-1 pad-1 convs on planes of 321..448 pixels (<= 21 x 21) with Cin, Cout multiples of 64 this is ONE
- * launch: the workgroup that owns an (image, 64-channel) plane of y normalises it in its epilogue (csrc/conv_plane.hip).
- * Other shapes run the two calls above back to back.  groups must be 1; act: none / relu / lrelu.                     */
+ * launch: the workgroup that owns an (image, 64-channel) plane of y normalises it in its epilogue (csrc/conv_plane.hip);
+ * so is it, without gamma / beta maps (plain InstanceNorm: gb_img == NULL), for the PatchGAN 4x4 stride-1 layers on planes
+ * of up to 192 pixels (csrc/conv_planeg.hip).  Other shapes run the two calls above back to back
+ * (s2p_conv2d_mat_is_fused tells which).  groups must be 1; act: none / relu / lrelu.                                 */
 int s2p_conv2d_fwd_mat(const s2p_conv_desc* d, const void* x, const void* w_fwd, const float* bias, const void* aux,
                        void* y, int epi, const void* gb_img, int gb_pitch, const float* gb_st, int gb_st_pitch,
                        int act, float slope, float eps, void* y_mat, int y_mat_pitch, float* stats, void* workspace,
@@ -103,15 +107,20 @@ int s2p_conv2d_fwd_mat(const s2p_conv_desc* d, const void* x, const void* w_fwd,
 /* The backward counterpart: dgrad of a conv whose INPUT was the output of a MAT norm, followed by that norm's backward
  * (s2p_conv2d_dgrad_ws + s2p_in_norm_bwd_res).  d describes the conv (forward orientation); dy = dL/d(conv output);
  * xn / stats / gb_img / gb_st / act: the norm's input, statistics and modulation as in s2p_in_norm_bwd; outputs
- * dxn = dL/d(xn) (+ res), dgb_img, dgb_st as there.  Under the conditions of s2p_conv2d_fwd_mat (on the dgrad: Cout is the
- * contraction, Cin the produced channels) this is ONE launch and dL/d(norm output) never reaches HBM; otherwise it is
- * written to d_mid ([N,H,W,x_pitch], always required) and the norm backward runs as its own launch(es) (needs `sums`:
+ * dxn = dL/d(xn) (+ res), dgb_img, dgb_st as there.  aux (may be NULL; layout of d_mid) is a second gradient arriving at
+ * the norm's OUTPUT (a feature-matching tap on the activation): it is added to the dgrad result before the norm backward.
+ * Under the conditions of s2p_conv2d_fwd_mat (on the dgrad: Cout is the contraction, Cin the produced channels) this is ONE
+ * launch and dL/d(norm output) never reaches HBM (d_mid and sums may then be NULL: s2p_conv2d_mat_is_fused); otherwise it
+ * is written to d_mid ([N,H,W,x_pitch]) and the norm backward runs as its own launch(es) (needs `sums`:
  * s2p_in_bwd_sums_floats(N, H*W, Cin) floats).                                                                        */
-int s2p_conv2d_dgrad_mat(const s2p_conv_desc* d, const void* dy, const void* w_bwd, void* d_mid, const void* xn,
+int s2p_conv2d_dgrad_mat(const s2p_conv_desc* d, const void* dy, const void* w_bwd, void* d_mid, const void* aux, const void* xn,
                          int xn_pitch, const float* stats, const void* gb_img, int gb_pitch, const float* gb_st,
                          int gb_st_pitch, int act, float slope, float eps, float* sums, void* dxn, int dxn_pitch,
                          void* dgb_img, int dgb_pitch, float* dgb_st, int dgb_st_pitch, const void* res, int res_pitch,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* 1 when s2p_conv2d_fwd_mat (dgrad == 0) / s2p_conv2d_dgrad_mat (dgrad == 1) run this problem as ONE fused launch (no d_mid / sums
+ * scratch needed), 0 when they fall back to two calls.  has_gb: gamma / beta image maps are passed.                    */
+int s2p_conv2d_mat_is_fused(const s2p_conv_desc* d, int dgrad, int has_gb);
 /* dw (fp32) [groups][Cout][KH*KW][Cin_real] for transposed==0,
  *           [groups][Cin][KH*KW][Cout_real] for transposed==1  (= channels-last physical
  * layout of the torch parameter).  dw is ACCUMULATED into (caller zeroes it);
@@ -326,6 +335,7 @@ int s2p_copy_channels(int dtype, const void* src, int src_pitch, int src_off, vo
 int s2p_image_metrics(const float* a, const float* b, int N, int C, int H, int W, float data_range,
                       float* sq_err_sum, float* ssim_sum, void* stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -53,8 +53,9 @@ SIGNATURES = {
     "s2p_conv2d_fwd_ws": [_DESC, _P, _P, _P, _P, _P, c_int, c_float, c_int, _P, ctypes.c_size_t, _P],
     "s2p_conv2d_fwd_mat": [_DESC, _P, _P, _P, _P, _P, c_int, _P, c_int, _P, c_int, c_int, c_float, c_float, _P, c_int, _P, _P,
                            ctypes.c_size_t, _P],
-    "s2p_conv2d_dgrad_mat": [_DESC, _P, _P, _P, _P, c_int, _P, _P, c_int, _P, c_int, c_int, c_float, c_float, _P, _P, c_int, _P, c_int,
+    "s2p_conv2d_dgrad_mat": [_DESC, _P, _P, _P, _P, _P, c_int, _P, _P, c_int, _P, c_int, c_int, c_float, c_float, _P, _P, c_int, _P, c_int,
                              _P, c_int, _P, c_int, _P, ctypes.c_size_t, _P],
+    "s2p_conv2d_mat_is_fused": [_DESC, c_int, c_int],
     "s2p_conv2d_dgrad_workspace": [_DESC],
     "s2p_conv2d_dgrad_ws": [_DESC, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P, ctypes.c_size_t, _P],
     "s2p_conv2d_wgrad": [_DESC, _P, _P, _P, _P, c_int, c_int, c_int64, c_int, _P],
@@ -136,7 +137,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the export is missing
             fn.argtypes = args
             fn.restype = _RESTYPE.get(name, c_int)
-        if L.s2p_version() < 114:
+        if L.s2p_version() < 115:
             raise RuntimeError("libs2p_hip.so is older than this package")
         _lib = L
     return _lib

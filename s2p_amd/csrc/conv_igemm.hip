@@ -13,6 +13,7 @@
 // per K step; epilogue goes through LDS so every global store is a full 16-B chunk along the channel axis.
 #include "s2p_common.h"
 #include "conv_plane.h"
+#include "conv_planeg.h"
 #include <type_traits>
 
 #define MAX_TAPS 64
@@ -1278,17 +1279,43 @@ static int launch_fast(GatherArgs& a, int groups, hipStream_t st) {
       p.act = a.act; p.epi = a.epi; p.gact = a.gact; p.slope = a.slope; p.gslope = a.gslope;
       p.x_bytes = a.x_bytes; p.w_bytes = a.w_bytes;
       if (s2p_conv_plane_applicable(p)) {
+        const bool fuse = a.mat && groups == 1 && a.act == S2P_ACT_NONE && a.epi != S2P_EPI_MUL_ACTGRAD && (!a.mat->xn || a.epi == S2P_EPI_STORE);
+        if (fuse) *a.mat_done = 1;
         if (a.plan) return 0;                              // no scratch
-        if (a.mat && groups == 1 && a.act == S2P_ACT_NONE && a.epi != S2P_EPI_MUL_ACTGRAD && (!a.mat->xn || a.epi == S2P_EPI_STORE)) {
+        if (fuse) {
           p.xn = a.mat->xn; p.xn_pitch = a.mat->xn_pitch; p.dgb = a.mat->dgb; p.dgb_pitch = a.mat->dgb_pitch;
           p.dgbst = a.mat->dgbst; p.dgbst_pitch = a.mat->dgbst_pitch; p.res = a.mat->res; p.res_pitch = a.mat->res_pitch;
           p.y2 = a.mat->y2; p.y2_pitch = a.mat->y2_pitch; p.gb = a.mat->gb; p.gb_pitch = a.mat->gb_pitch;
           p.gbst = a.mat->gbst; p.gbst_pitch = a.mat->gbst_pitch; p.stats = a.mat->stats;
           p.n_act = a.mat->act; p.n_slope = a.mat->slope; p.eps = a.mat->eps;
-          *a.mat_done = 1;
         }
         return s2p_conv_plane_launch(p, groups, st);
       }
+    }
+  }
+  // other small planes -- the PatchGAN 4x4 layers and their stride-1 dgrads: the generalised plane-resident kernel (conv_planeg.hip),
+  // with the InstanceNorm that follows (forward) / precedes (backward) the conv in its epilogue
+  if (!no_plane && !no_dma && groups == 1 && a.nphase == 0 && a.T != 9 && a.ostride == 1 && a.oy0 == 0 && a.ox0 == 0 && a.Qh == a.Ho &&
+      a.Qw == a.Wo && a.M % (a.Qh * a.Qw) == 0 && !a.reflect) {
+    PlaneGProblem pr{a.M / (a.Qh * a.Qw), a.Hi, a.Wi, a.Ho, a.Wo, a.Cin, a.Cout, a.Cst, a.x_pitch, a.y_pitch, a.istride, a.T, a.tap};
+    PlaneGArgs p{};
+    if (s2p_conv_planeg_setup(pr, p)) {
+      const bool fuse = a.mat && !a.mat->gb && a.act == S2P_ACT_NONE && a.epi != S2P_EPI_MUL_ACTGRAD;
+      if (fuse) *a.mat_done = 1;
+      if (a.plan) return 0;                                // no scratch
+      p.x = a.x; p.w = a.w; p.bias = a.bias; p.aux = a.aux; p.aux2 = a.aux2; p.y = a.y;
+      p.N = pr.N; p.Cin = a.Cin; p.x_pitch = a.x_pitch; p.x_gstride = a.x_gstride;
+      p.Cout = a.Cout; p.Cst = a.Cst; p.y_pitch = a.y_pitch; p.y_gstride = a.y_gstride;
+      p.w_row = a.w_row; p.w_gstride = a.w_gstride;
+      p.act = a.act; p.epi = a.epi; p.gact = a.gact; p.slope = a.slope; p.gslope = a.gslope;
+      p.x_bytes = a.x_bytes; p.w_bytes = a.w_bytes;
+      if (fuse) {
+        p.xn = a.mat->xn; p.xn_pitch = a.mat->xn_pitch; p.dgb = a.mat->dgb; p.dgb_pitch = a.mat->dgb_pitch;
+        p.dgbst = a.mat->dgbst; p.dgbst_pitch = a.mat->dgbst_pitch; p.res = a.mat->res; p.res_pitch = a.mat->res_pitch;
+        p.y2 = a.mat->y2; p.y2_pitch = a.mat->y2_pitch; p.gbst = a.mat->gbst; p.gbst_pitch = a.mat->gbst_pitch; p.stats = a.mat->stats;
+        p.n_act = a.mat->act; p.n_slope = a.mat->slope; p.eps = a.mat->eps;
+      }
+      return s2p_conv_planeg_launch(p, groups, st);
     }
   }
   if constexpr (BCO == 128 && BPIX == 128) {
@@ -1598,24 +1625,40 @@ extern "C" int s2p_conv2d_dgrad_ws(const s2p_conv_desc* d, const void* dy, const
                                    size_t workspace_bytes, void* stream) {
   return conv_dgrad_impl(d, dy, w_bwd, aux, aux2, dx, epi, aux_act, slope, Scratch{workspace, workspace_bytes, nullptr}, stream);
 }
-extern "C" int s2p_conv2d_dgrad_mat(const s2p_conv_desc* d, const void* dy, const void* w_bwd, void* d_mid, const void* xn,
+extern "C" int s2p_conv2d_dgrad_mat(const s2p_conv_desc* d, const void* dy, const void* w_bwd, void* d_mid, const void* aux, const void* xn,
                                     int xn_pitch, const float* stats, const void* gb_img, int gb_pitch, const float* gb_st,
                                     int gb_st_pitch, int act, float slope, float eps, float* sums, void* dxn, int dxn_pitch,
                                     void* dgb_img, int dgb_pitch, float* dgb_st, int dgb_st_pitch, const void* res, int res_pitch,
                                     void* workspace, size_t workspace_bytes, void* stream) {
-  if (!d || !d_mid || !xn || !stats || !dxn) S2P_FAIL(-1, "s2p_conv2d_dgrad_mat: null pointer");
+  if (!d || !xn || !stats || !dxn) S2P_FAIL(-1, "s2p_conv2d_dgrad_mat: null pointer");
   if (act != S2P_ACT_NONE && act != S2P_ACT_RELU && act != S2P_ACT_LRELU) S2P_FAIL(-1, "s2p_conv2d_dgrad_mat: activation must be none / relu / lrelu");
   if (d->groups != 1 || d->transposed || d->reflect) S2P_FAIL(-1, "s2p_conv2d_dgrad_mat: groups == 1, not transposed, zero padding");
+  if (d->Cin != d->x_pitch) S2P_FAIL(-1, "s2p_conv2d_dgrad_mat: the produced tensor must be dense (x_pitch %d != Cin %d)", d->x_pitch, d->Cin);
   PlaneMat m{dxn, dxn_pitch, gb_img, gb_pitch, gb_st, gb_st_pitch, const_cast<float*>(stats), act, slope, eps,
              xn, xn_pitch, dgb_img, dgb_pitch, dgb_st, dgb_st_pitch, res, res_pitch};
+  if (!d_mid || !sums) {                  // scratch of the two-launch form left out: the caller relies on the fused kernel
+    if (!s2p_conv2d_mat_is_fused(d, 1, gb_img != nullptr))
+      S2P_FAIL(-1, "s2p_conv2d_dgrad_mat: this shape runs as two launches and needs d_mid and sums (s2p_conv2d_mat_is_fused)");
+  }
   int done = 0;
-  int rc = conv_dgrad_impl(d, dy, w_bwd, nullptr, nullptr, d_mid, S2P_EPI_STORE, S2P_ACT_NONE, 0.f,
+  int rc = conv_dgrad_impl(d, dy, w_bwd, aux, nullptr, d_mid ? d_mid : dxn, aux ? S2P_EPI_ADD : S2P_EPI_STORE, S2P_ACT_NONE, 0.f,
                            Scratch{workspace, workspace_bytes, nullptr, &m, &done}, stream);
   if (rc || done) return rc;
-  // shapes the plane-resident kernel does not take: the dgrad above wrote d_mid; the norm backward as its own launch(es)
+  if (!d_mid || !sums) S2P_FAIL(-1, "s2p_conv2d_dgrad_mat: not fused for these arguments (an aux gradient fuses only on the 4x4 family): d_mid and sums are required");
+  // shapes the plane-resident kernels do not take: the dgrad above wrote d_mid; the norm backward as its own launch(es)
   return s2p_in_norm_bwd_res(d->dtype, d_mid, d->x_pitch, xn, d->N, d->H * d->W, d->Cin, xn_pitch, stats, gb_img, gb_pitch, gb_st,
                              gb_st_pitch, act, slope, eps, sums, dxn, dxn_pitch, dgb_img, dgb_pitch, dgb_st, dgb_st_pitch, res,
                              res_pitch, stream);
+}
+extern "C" int s2p_conv2d_mat_is_fused(const s2p_conv_desc* d, int dgrad, int has_gb) {
+  if (!d || d->groups != 1 || d->transposed || d->reflect) return 0;
+  static const char dummy[16] = {0};
+  PlaneMat m{};
+  m.y2 = (void*)dummy; m.gb = has_gb ? dummy : nullptr; m.xn = dgrad ? dummy : nullptr;
+  int done = 0; size_t need = 0;
+  const int rc = dgrad ? conv_dgrad_impl(d, nullptr, nullptr, nullptr, nullptr, nullptr, S2P_EPI_STORE, S2P_ACT_NONE, 0.f, Scratch{nullptr, 0, &need, &m, &done}, nullptr)
+                       : conv_fwd_impl(d, nullptr, nullptr, nullptr, nullptr, nullptr, S2P_ACT_NONE, 0.f, S2P_EPI_STORE, Scratch{nullptr, 0, &need, &m, &done}, nullptr);
+  return rc == 0 && done ? 1 : 0;
 }
 extern "C" size_t s2p_conv2d_dgrad_workspace(const s2p_conv_desc* d) {
   size_t need = 0;

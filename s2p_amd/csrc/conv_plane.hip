@@ -33,7 +33,7 @@ __device__ __forceinline__ void pl_static_for(F&& f) {
 // lane (voffset >= num_records) still returns zeros.
 __device__ __forceinline__ void pl_dma16(i32x4 rsrc, unsigned lds_dst, int voffset, int soffset) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
-               :: "v"(voffset), "s"(rsrc), "s"(lds_dst), "s"(soffset) : "memory");
+               :: "v"(voffset), "s"(rsrc), "s"(lds_dst), "s"(soffset) : "memory", "m0");
 }
 
 namespace {

@@ -126,10 +126,11 @@ __device__ __forceinline__ unsigned s2p_lds_addr(const void* p) {
   return (unsigned)(unsigned long long)((__attribute__((address_space(3))) const char*)p);
 }
 // lds_dst: wave-uniform LDS byte address of this wave's 1-KiB piece; voffset: this lane's byte offset into the buffer
-// (an offset >= the descriptor's size returns zeros).  M0 is written in the same statement that consumes it.
+// (an offset >= the descriptor's size returns zeros).  M0 is written in the same statement that consumes it and is declared
+// clobbered: the compiler may keep nothing of its own in M0 across a DMA.
 __device__ __forceinline__ void s2p_dma16(i32x4 rsrc, unsigned lds_dst, int voffset) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
-               :: "v"(voffset), "s"(rsrc), "s"(lds_dst) : "memory");
+               :: "v"(voffset), "s"(rsrc), "s"(lds_dst) : "memory", "m0");
 }
 #define S2P_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 

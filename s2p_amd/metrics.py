@@ -20,9 +20,8 @@ def _prep(a, b):
 
 def image_metrics(a, b, data_range=2.0):
     """a, b: NCHW frames (default range [-1,1] -> data_range 2).  Returns (psnr [N], ssim [N]) fp32 device tensors.
-    psnr is +inf for identical images.
-    Run it on the stream that produced the frames (or on an idle device), not beside training launches on another stream:
-    the SSIM sums were observed ~1 % off while the slab weight-gradient kernel shared the CUs (open)."""
+    psnr is +inf for identical images.  The kernel uses no LDS: it may run on any stream, also beside
+    training launches."""
     a, b = _prep(a, b)
     N, C, H, W = a.shape
     acc = torch.zeros((2, N), dtype=torch.float32, device=a.device)

@@ -63,9 +63,8 @@ class NLayerDiscriminator(BaseNetwork):
         feats, saved = [f], [(x, None, None, f)]
         for n in range(1, nl):
             xin = f
-            c = self.lay[n].fwd(xin)
-            C = self.chans[n]
-            f, s = ops.in_norm_fwd(c, C, act=ACT_LRELU, slope=LRELU)
+            # conv -> InstanceNorm -> LeakyReLU: ONE launch where a plane-resident kernel takes the layer (s2p_conv2d_fwd_mat)
+            c, f, s = self.lay[n].fwd_mat(xin, None, 0, None, 0, ACT_LRELU, LRELU)
             feats.append(f)
             saved.append((xin, c, s, f))
         out = self.lay[nl].fwd(f)
@@ -87,19 +86,18 @@ class NLayerDiscriminator(BaseNetwork):
             raise RuntimeError("discriminator backward needs a gradient for the final logit map")
         if need_wgrad:
             self.lay[nl].wgrad(xin, g)
-        gprev = grads[nl - 1]
-        d = self.lay[nl].dgrad(g, xin.shape, aux=gprev, epi=EPI_ADD if gprev is not None else EPI_STORE)
+        # dgrad of layer n + 1 -> (+ the tap gradient on feature n) -> backward of layer n's InstanceNorm + LeakyReLU: one call
+        # (s2p_conv2d_dgrad_mat: ONE launch where a plane-resident kernel takes the dgrad), giving dL/d(conv_n output)
+        dy, lay_next = g, self.lay[nl]
         for n in reversed(range(1, nl)):
             xin, c, s, f = saved[n]
-            dc = ops.in_bwd(d, c, self.chans[n], s, act=ACT_LRELU, slope=LRELU)
+            dc = lay_next.dgrad_mat(dy, c, s, None, 0, None, 0, ACT_LRELU, LRELU, None, 0, None, 0, aux=grads[n])
             if need_wgrad:
                 self.lay[n].wgrad(xin, dc)
-            gprev = grads[n - 1]
-            if n == 1:      # xin = f0 = LeakyReLU(conv0): fold the tap gradient and the LeakyReLU mask into the epilogue
-                d = self.lay[n].dgrad(dc, xin.shape, aux=xin, aux2=gprev, epi=EPI_MUL_ACTGRAD, aux_act=ACT_LRELU,
-                                      slope=LRELU)
-            else:
-                d = self.lay[n].dgrad(dc, xin.shape, aux=gprev, epi=EPI_ADD if gprev is not None else EPI_STORE)
+            dy, lay_next = dc, self.lay[n]
+        # layer 1's dgrad: xin = f0 = LeakyReLU(conv0): fold the tap gradient and the LeakyReLU mask into the epilogue
+        xin = saved[1][0]
+        d = self.lay[1].dgrad(dy, xin.shape, aux=xin, aux2=grads[0], epi=EPI_MUL_ACTGRAD, aux_act=ACT_LRELU, slope=LRELU)
         x, _, _, f0 = saved[0]
         dpre = d
         if need_wgrad:

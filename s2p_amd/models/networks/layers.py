@@ -53,11 +53,11 @@ class ConvLayer:
         return ops.conv_dgrad(self.geom, dy, self.pk.w_bwd, tuple(x_shape), self.cin_pad(dy.dtype), aux=aux, epi=epi,
                               aux_act=aux_act, slope=slope, aux2=aux2)
 
-    def dgrad_mat(self, dy, xn, stats, gb, gb_off, gb_st, st_off, act, slope, dgb, dgb_off, dgb_st, dst_off, res=None):
+    def dgrad_mat(self, dy, xn, stats, gb, gb_off, gb_st, st_off, act, slope, dgb, dgb_off, dgb_st, dst_off, res=None, aux=None):
         """dgrad of this conv followed by the backward of the MAT norm that produced its input (one launch where the
         plane-resident kernel applies): returns dL/d(norm input) (+ res)."""
         return ops.conv_dgrad_mat(self.geom, dy, self.pk.w_bwd, xn, self.cin_pad(dy.dtype), stats, gb, gb_off, gb_st, st_off,
-                                  act, slope, dgb, dgb_off, dgb_st, dst_off, res=res)
+                                  act, slope, dgb, dgb_off, dgb_st, dst_off, res=res, aux=aux)
 
     def wgrad(self, x, dy):
         """Accumulate weight (and bias) gradients straight into the flat grad buffer."""

@@ -130,6 +130,7 @@ def conv_fwd_mat(geom, x, w_fwd, bias, cin_pad, gb, gb_off, gb_st, st_off, act=A
     pr = _Prof("fwd", geom, N, H, W, x.dtype)
     if pr.on:       # the fused launch also moves the norm's bytes: gamma, beta read + the modulated tensor written
         pr.rec["norm_bytes"] = float(N * Ho * Wo * C * x.element_size() * 3)
+        pr.rec["variant"] = "mat_fwd"
     check(lib().s2p_conv2d_fwd_mat(ctypes.byref(d), ptr(x), ptr(w_fwd), ptr(bias), ptr(aux), ptr(y), epi, gbp, gb_pitch, stp,
                                    st_pitch, act, slope, IN_EPS, ptr(y_mat), C, ptr(stats), ptr(ws), need, stream()),
           "s2p_conv2d_fwd_mat")
@@ -172,15 +173,20 @@ def conv_dgrad(geom, dy, w_bwd, x_shape, cin_pad, aux=None, epi=EPI_STORE, aux_a
 
 
 def conv_dgrad_mat(geom, dy, w_bwd, xn, cin_pad, stats, gb, gb_off, gb_st, st_off, act, slope, dgb, dgb_off, dgb_st, dst_off,
-                   res=None):
-    """dgrad of a conv whose input was a MAT norm's output, fused with that norm's backward (s2p_conv2d_dgrad_mat):
-    returns dL/d(xn) (+ res); writes d(gamma|beta) as in_bwd does.  xn: the norm's input [N,H,W,C]."""
+                   res=None, aux=None):
+    """dgrad of a conv whose input was a MAT / InstanceNorm's output, fused with that norm's backward (s2p_conv2d_dgrad_mat):
+    returns dL/d(xn) (+ res); writes d(gamma|beta) as in_bwd does.  xn: the norm's input [N,H,W,C].  aux: a second gradient
+    arriving at the norm's output (layout of the dgrad result), added before the norm backward."""
     N, H, W, xp = xn.shape
     C = geom.cin
+    if cin_pad != C or xp != C:
+        raise ValueError("conv_dgrad_mat: the norm's tensor must be dense in channels (C %d, cin_pad %d, pitch %d)" % (C, cin_pad, xp))
     d = geom.desc(dy.dtype, N, H, W, cin_pad, C, dy.shape[3])
     dxn = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
-    d_mid = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)      # only touched on the two-launch path
-    sums = torch.empty(lib().s2p_in_bwd_sums_floats(N, H * W, C), dtype=torch.float32, device=dy.device)
+    fused = bool(lib().s2p_conv2d_mat_is_fused(ctypes.byref(d), 1, int(gb is not None))) and (aux is None or geom.k != 3)
+    # scratch of the two-launch form only when that form runs
+    d_mid = None if fused else torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
+    sums = None if fused else torch.empty(lib().s2p_in_bwd_sums_floats(N, H * W, C), dtype=torch.float32, device=dy.device)
     need = lib().s2p_conv2d_dgrad_workspace(ctypes.byref(d))
     ws = torch.empty(need, dtype=torch.uint8, device=dy.device) if need else None
     gbp, gb_pitch, stp, st_pitch = _gb_args(gb, gb_off, gb_st, st_off)
@@ -189,8 +195,14 @@ def conv_dgrad_mat(geom, dy, w_bwd, xn, cin_pad, stats, gb, gb_off, gb_st, st_of
     _ = ptr(dgb), ptr(dgb_st)
     if res is not None:
         assert res.shape == dxn.shape and res.dtype == dxn.dtype and res.is_contiguous()
+    if aux is not None:
+        assert aux.shape == dxn.shape and aux.dtype == dxn.dtype and aux.is_contiguous()
     pr = _Prof("dgrad", geom, N, H, W, dy.dtype)
-    check(lib().s2p_conv2d_dgrad_mat(ctypes.byref(d), ptr(dy), ptr(w_bwd), ptr(d_mid), ptr(xn), xp, ptr(stats), gbp, gb_pitch,
+    if pr.on:       # + the norm backward's bytes: xn, gamma, beta read (+ res, aux), dxn, d(gamma), d(beta) written; dy is the conv's own
+        nt = (2 + (res is not None) + (aux is not None)) if gb is None else (6 + (res is not None) + (aux is not None))
+        pr.rec["norm_bytes"] = float(N * H * W * C * dy.element_size() * nt)
+        pr.rec["variant"] = "mat_bwd"
+    check(lib().s2p_conv2d_dgrad_mat(ctypes.byref(d), ptr(dy), ptr(w_bwd), ptr(d_mid), ptr(aux), ptr(xn), xp, ptr(stats), gbp, gb_pitch,
                                      stp, st_pitch, act, slope, IN_EPS, ptr(sums), ptr(dxn), C, dgbp,
                                      dgb.shape[3] if dgb is not None else 0, dstp,
                                      dgb_st.shape[1] if dgb_st is not None else 0, ptr(res), C if res is not None else 0,

@@ -814,6 +814,81 @@ def test_conv_plane_kernels_epilogues_and_groups(hip_device, N, HW_):
     assert rel_err(dw_b.view(G * co, 3, 3, ci).permute(0, 3, 1, 2).cpu(), refw) < TOL[dtype]
 
 
+@pytest.mark.parametrize("residual", [False, True])
+def test_plane_kernels_production_shape(hip_device, residual):
+    """The production shapes of the timed workload (missing #2), at full size, against float64 on samples
+    {0, 21, 42, 63} (every op is per-sample): (64, 256, 256, 21, 21) bf16 through s2p_conv2d_fwd_mat -- the fused
+    `conv_plane_kernel<7,22,0,1>` on its (N & 7) == 0 XCD-remap branch, one workgroup per CU -- and through
+    s2p_conv2d_dgrad_mat (`<7,22,0,2>`)."""
+    dev = hip_device
+    dtype = torch.bfloat16
+    N, C, H, W = 64, 256, 21, 21
+    pick = [0, 21, 42, 63]
+    g = torch.Generator().manual_seed(17)
+    r = lambda *sh: torch.randn(*sh, generator=g).bfloat16().float()      # noqa: E731
+    x, w, b = r(N, C, H, W), r(C, C, 3, 3) / math.sqrt(C * 9), torch.randn(C, generator=g)
+    gb = r(N, 2 * C, H, W) * 0.5
+    st = torch.randn(N, 2 * C, generator=g) * 0.5
+    geom = ops.ConvGeom(C, C, 3, 1, 1)
+    xd, wf, wb = nhwc(x, C, dtype, dev), pack_fwd(w, C, dtype, dev), pack_bwd(w, C, C, dtype, dev)
+    gbd, std = nhwc(gb, 2 * C, dtype, dev), st.to(dev)
+    y, ym, stats = ops.conv_fwd_mat(geom, xd, wf, b.to(dev), C, gbd, 0, std, 0, act=ACT_LRELU, slope=0.2,
+                                    aux=xd if residual else None, epi=EPI_ADD if residual else EPI_STORE)
+    torch.cuda.synchronize()
+    xs = x[pick].double()
+    y_ref = F.conv2d(xs, w.double(), b.double(), padding=1) + (xs if residual else 0)
+    assert rel_err(nchw(y, C)[pick], y_ref) < TOL[dtype]
+    ys = nchw(y, C)[pick].double()                               # the norm acts on the tensor the kernel STORED
+    xh = F.instance_norm(ys, eps=1e-5)
+    gam = gb[pick, :C].double() + st[pick, :C].double()[:, :, None, None]
+    bet = gb[pick, C:].double() + st[pick, C:].double()[:, :, None, None]
+    assert rel_err(nchw(ym, C)[pick], F.leaky_relu(xh * (1 + gam) + bet, 0.2)) < 6e-3
+    # backward form: dgrad of a conv fed by norm(xn) -> norm backward (+ skip gradient)
+    dy, res = r(N, C, H, W), r(N, C, H, W)
+    xnd, dyd = xd, nhwc(dy, C, dtype, dev)
+    _, stats_n = ops.in_norm_fwd(xnd, C, gbd, 0, std, 0, ACT_LRELU, 0.2)
+    dgb = torch.zeros_like(gbd); dst = torch.zeros_like(std)
+    dx = ops.conv_dgrad_mat(geom, dyd, wb, xnd, C, stats_n, gbd, 0, std, 0, ACT_LRELU, 0.2, dgb, 0, dst, 0,
+                            res=nhwc(res, C, dtype, dev) if residual else None)
+    torch.cuda.synchronize()
+    xr = x[pick].double().requires_grad_(True); gbr = gb[pick].double().requires_grad_(True); str_ = st[pick].double().requires_grad_(True)
+    gam = gbr[:, :C] + str_[:, :C][:, :, None, None]
+    bet = gbr[:, C:] + str_[:, C:][:, :, None, None]
+    F.conv2d(F.leaky_relu(F.instance_norm(xr, eps=1e-5) * (1 + gam) + bet, 0.2), w.double(), padding=1).backward(dy[pick].double())
+    assert rel_err(nchw(dx, C)[pick], xr.grad + (res[pick].double() if residual else 0)) < TOL[dtype]
+    assert rel_err(nchw(dgb, 2 * C)[pick], gbr.grad) < TOL[dtype]
+    assert rel_err(dst.cpu()[pick], str_.grad) < 1e-2
+
+
+def test_plane_pair_kernel_production_groups(hip_device):
+    """The generator's gamma|beta conv at full size: 12 groups of 128 -> 512 at N = 64, 21x21, group-major output (24 tiles per
+    CU: `conv_plane_pair_kernel`), forward and dgrad against float64 on samples {0, 21, 42, 63} of groups {0, 5, 11}."""
+    dev = hip_device
+    dtype = torch.bfloat16
+    N, H, W, G, ci, co = 64, 21, 21, 12, 128, 512
+    pick, gpick = [0, 21, 42, 63], [0, 5, 11]
+    g = torch.Generator().manual_seed(19)
+    r = lambda *sh: torch.randn(*sh, generator=g).bfloat16().float()      # noqa: E731
+    xg, wg, bg = r(N, G * ci, H, W), r(G * co, ci, 3, 3) / math.sqrt(ci * 9), torch.randn(G * co, generator=g)
+    ggm = ops.ConvGeom(ci, co, 3, 1, 1, groups=G, x_gstride=ci, y_gstride=N * H * W * co)
+    wfg = torch.stack([pack_fwd(wg[i * co:(i + 1) * co], ci, dtype, dev) for i in range(G)])
+    wbg = torch.stack([pack_bwd(wg[i * co:(i + 1) * co], ci, co, dtype, dev) for i in range(G)])
+    xd = nhwc(xg, G * ci, dtype, dev)
+    y5 = torch.full((G, N, H, W, co), float("nan"), dtype=dtype, device=dev)
+    ops.conv_fwd(ggm, xd, wfg, bg.to(dev), ci, y_pitch=co, act=ACT_NONE, out=y5[0])
+    dy5 = torch.randn(G, N, H, W, co, generator=g).to(dtype).to(dev)
+    dx = ops.conv_dgrad(ggm, dy5[0], wbg, (N, H, W, G * ci), ci)
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(y5.float()).any())
+    for i in gpick:
+        wi = wg[i * co:(i + 1) * co].double()
+        ref = F.conv2d(xg[pick, i * ci:(i + 1) * ci].double(), wi, bg[i * co:(i + 1) * co].double(), padding=1)
+        assert rel_err(nchw(y5[i], co)[pick], ref) < TOL[dtype], i
+        dyi = dy5[i].float().cpu().permute(0, 3, 1, 2)[pick].double()
+        refd = F.conv_transpose2d(dyi, wi, padding=1)
+        assert rel_err(nchw(dx, G * ci)[pick, i * ci:(i + 1) * ci], refd) < TOL[dtype], i
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_pack_weights_against_torch(hip_device, dtype):
     """s2p_pack_weights (csrc/misc.hip): fp32 channels-last master [R][T][C] -> the forward operand [R][T][Cpad] (zero pad) and the

@@ -1,5 +1,5 @@
 """Disassemble the gfx950 code objects embedded in libs2p_hip.so (no GPU needed) and tabulate, per kernel, its LDS (DS)
-instructions and whether it stages through LDS-DMA.  Used by tests/test_host_logic.py::test_lds_access_widths and as a tool:
+instructions, whether it stages through LDS-DMA, and its packed-fp32 / op_sel instructions (the hazard class of DESIGN.md section 4).  Used by tests/test_host_logic.py::test_lds_access_widths and as a tool:
     python tests/tools/isa_audit.py [path/to/libs2p_hip.so]"""
 import collections, os, re, struct, subprocess, sys, tempfile
 
@@ -61,7 +61,7 @@ def audit(so_path):
             if m:
                 cur = m.group(1)
                 if not cur.endswith(".kd"):
-                    res.setdefault(cur, {"ds": collections.Counter(), "lds_dma": 0})
+                    res.setdefault(cur, {"ds": collections.Counter(), "lds_dma": 0, "packed": collections.Counter()})
                 continue
             if cur is None or cur not in res:
                 continue
@@ -69,6 +69,8 @@ def audit(so_path):
             if not ins:
                 continue
             op = ins[0]
+            if re.match(r"v_pk_\w+_f32", op) or "op_sel" in line:
+                res[cur]["packed"][op + (" op_sel" if "op_sel" in line else "")] += 1
             if op.startswith("ds_"):
                 res[cur]["ds"][op] += 1
             elif (op.startswith("buffer_load") or op.startswith("global_load_lds")) and (" lds" in line or op.startswith("global_load_lds")):
