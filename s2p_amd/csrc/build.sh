@@ -13,17 +13,24 @@
 set -e
 cd "$(dirname "$0")"
 OUT=libs2p_hip.so; SUF=""; EXTRA=""
-if [ "$1" = "diag" ]; then OUT=libs2p_hip_diag.so; SUF=".diag"; EXTRA="-DS2P_DIAG_BUILD"; shift; fi
+DIAG_SRCS=""
+if [ "$1" = "diag" ]; then OUT=libs2p_hip_diag.so; SUF=".diag"; EXTRA="-DS2P_DIAG_BUILD"; DIAG_SRCS="diag_probe.hip"; shift; fi
 SRCS="conv_igemm.hip conv_plane.hip conv_planeg.hip wgrad_igemm.hip wgrad_slab.hip wgrad_head.hip linear_small.hip norm.hip misc.hip thin_conv.hip thin_rows.hip metrics.hip"
-newest=$(ls -t $SRCS s2p_common.h conv_plane.h conv_planeg.h ../../include/s2p_hip.h build.sh | head -1)
+NOPK="-Xclang -target-feature -Xclang -packed-fp32-ops"
+newest=$(ls -t $SRCS $DIAG_SRCS s2p_common.h conv_plane.h conv_planeg.h ../../include/s2p_hip.h build.sh | head -1)
 if [ -z "$FORCE" ] && [ -f "$OUT" ] && [ "$OUT" -nt "$newest" ]; then echo "up to date: $(pwd)/$OUT"; exit 0; fi
 pids=(); objs=""
-for s in $SRCS; do
+for s in $SRCS $DIAG_SRCS; do
   o="${s%.hip}${SUF}.o"; objs="$objs $o"
-  hipcc --offload-arch=gfx950 -O3 -fPIC -fvisibility=hidden -std=c++17 -Wno-unused-value -Wno-inline-asm -Xclang -target-feature -Xclang -packed-fp32-ops $EXTRA -c "$s" -o "$o" "$@" \
+  pk="$NOPK"; if [ "$s" = "diag_probe.hip" ]; then pk=""; fi       # the probe file executes packed fp32 instructions on purpose
+  rm -f "$o"
+  hipcc --offload-arch=gfx950 -O3 -fPIC -fvisibility=hidden -std=c++17 -Wno-unused-value -Wno-inline-asm $pk $EXTRA -c "$s" -o "$o" "$@" \
     2> >(grep -v "is not a recognized feature for this target" >&2) &      # (the host half of the compile does not know the device feature)
   pids+=($!)
 done
-for p in "${pids[@]}"; do wait $p; done
+fail=0
+for p in "${pids[@]}"; do wait $p || fail=1; done
+for o in $objs; do [ -f "$o" ] || fail=1; done
+if [ $fail -ne 0 ]; then echo "build.sh: a compile failed" >&2; exit 1; fi
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" $objs
 echo "built $(pwd)/$OUT"

@@ -814,6 +814,69 @@ def test_conv_plane_kernels_epilogues_and_groups(hip_device, N, HW_):
     assert rel_err(dw_b.view(G * co, 3, 3, ci).permute(0, 3, 1, 2).cpu(), refw) < TOL[dtype]
 
 
+@pytest.mark.parametrize("shape", [
+    (8, 256, 512, 12, 12),      # PatchGAN 256 -> 512 4x4 stride 1 pad 2 on the finer scale's 12x12 map: 169-px planes, 3 pixel blocks per wave
+    (3, 64, 128, 7, 7),         # ... the coarser scale's 7x7 map: 64-px planes, one pixel block per wave; N % 8 != 0
+    (5, 128, 64, 11, 10),       # ragged plane 12 x 11, one output slab
+    (64, 256, 512, 12, 12),     # the production batch (XCD-remap branch), references on 4 samples
+])
+def test_conv_planeg_4x4_stride1(hip_device, shape):
+    """The generalised plane-resident kernel (csrc/conv_planeg.hip) on the PatchGAN 4x4 stride-1 layers, against float64:
+    forward (plain, and conv -> InstanceNorm -> LeakyReLU in ONE launch through s2p_conv2d_fwd_mat), dgrad (plain, and
+    dgrad (+ tap gradient) -> InstanceNorm / LeakyReLU backward in ONE launch through s2p_conv2d_dgrad_mat)."""
+    import ctypes
+    from s2p_amd import _lib
+    dev = hip_device
+    dtype = torch.bfloat16
+    N, cin, cout, H, W = shape
+    pick = list(range(N)) if N <= 8 else [0, 21, 42, 63]
+    g = torch.Generator().manual_seed(23)
+    r = lambda *sh: torch.randn(*sh, generator=g).bfloat16().float()      # noqa: E731
+    x, w = r(N, cin, H, W), r(cout, cin, 4, 4) / math.sqrt(cin * 16)
+    geom = ops.ConvGeom(cin, cout, 4, 1, 2)
+    Ho, Wo = geom.out_hw(H, W)
+    d = geom.desc(dtype, N, H, W, cin, cin, cout)
+    assert _lib.lib().s2p_conv2d_mat_is_fused(ctypes.byref(d), 0, 0) == 1 and _lib.lib().s2p_conv2d_mat_is_fused(ctypes.byref(d), 1, 0) == 1
+    xd, wf, wb = nhwc(x, cin, dtype, dev), pack_fwd(w, cin, dtype, dev), pack_bwd(w, cin, cout, dtype, dev)
+    # forward
+    y = ops.conv_fwd(geom, xd, wf, None, cin, act=ACT_LRELU, slope=0.2)
+    y_ref = F.conv2d(x[pick].double(), w.double(), padding=2)
+    assert rel_err(nchw(y, cout)[pick], F.leaky_relu(y_ref, 0.2)) < TOL[dtype]
+    c, f, stats = ops.conv_fwd_mat(geom, xd, wf, None, cin, None, 0, None, 0, act=ACT_LRELU, slope=0.2)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(c, cout)[pick], y_ref) < TOL[dtype]
+    cs = nchw(c, cout)[pick].double()                           # the norm acts on the tensor the kernel STORED
+    assert rel_err(nchw(f, cout)[pick], F.leaky_relu(F.instance_norm(cs, eps=1e-5), 0.2)) < 6e-3
+    f2, stats2 = ops.in_norm_fwd(c, cout, act=ACT_LRELU, slope=0.2)      # the separate norm launch: same tensor, same statistics
+    assert rel_err(f.float().cpu(), f2.float().cpu().double()) < 6e-3
+    hdr = stats[:2].view(torch.int32).cpu().tolist()           # norm.hip's self-describing format: {splits, rows per split}
+    assert hdr == [1, Ho * Wo]
+    mom = stats[4:4 + N * cout * 2].view(N, cout, 2).cpu()[pick].double()
+    assert rel_err(mom[..., 0], cs.mean((2, 3))) < 1e-4 and rel_err(mom[..., 1], cs.var((2, 3), unbiased=False) * (Ho * Wo)) < 1e-3
+    # dgrad: dy on the Ho x Wo grid -> dx on H x W
+    dy = r(N, cout, Ho, Wo)
+    dyd = nhwc(dy, cout, dtype, dev)
+    dx = ops.conv_dgrad(geom, dyd, wb, tuple(xd.shape), cin)
+    assert rel_err(nchw(dx, cin)[pick], F.conv_transpose2d(dy[pick].double(), w.double(), padding=2)) < TOL[dtype]
+    # dgrad (+ tap gradient on the activation) -> backward of InstanceNorm + LeakyReLU of the layer in front (its output = x here)
+    xn, tap = (r(N, cin, H, W) * 1.5 + 0.3).bfloat16().float(), r(N, cin, H, W)      # (bf16-exact: the reference sees the same branches)
+    xnd, tapd = nhwc(xn, cin, dtype, dev), nhwc(tap, cin, dtype, dev)
+    _, st_n = ops.in_norm_fwd(xnd, cin, act=ACT_LRELU, slope=0.2)
+    for with_tap in (False, True):
+        dxn = ops.conv_dgrad_mat(geom, dyd, wb, xnd, cin, st_n, None, 0, None, 0, ACT_LRELU, 0.2, None, 0, None, 0,
+                                 aux=tapd if with_tap else None)
+        torch.cuda.synchronize()
+        xr = xn[pick].double().requires_grad_(True)
+        a = F.leaky_relu(F.instance_norm(xr, eps=1e-5), 0.2)
+        loss = (F.conv2d(a, w.double(), padding=2) * dy[pick].double()).sum() + ((a * tap[pick].double()).sum() if with_tap else 0)
+        loss.backward()
+        assert rel_err(nchw(dxn, cin)[pick], xr.grad) < TOL[dtype], with_tap
+        # and the two separate launches
+        d_mid = ops.conv_dgrad(geom, dyd, wb, tuple(xd.shape), cin, aux=tapd if with_tap else None, epi=EPI_ADD if with_tap else EPI_STORE)
+        dx2 = ops.in_bwd(d_mid, xnd, cin, st_n, act=ACT_LRELU, slope=0.2)
+        assert rel_err(dxn.float().cpu(), dx2.float().cpu().double()) < 1e-2
+
+
 @pytest.mark.parametrize("residual", [False, True])
 def test_plane_kernels_production_shape(hip_device, residual):
     """The production shapes of the timed workload (missing #2), at full size, against float64 on samples

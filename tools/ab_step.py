@@ -1,6 +1,7 @@
 """Same-box A/B of Python-level switches on the full train step (box-to-box spread on this pool is +-3 %, so variants are
 compared inside ONE process: capture A, time it, capture B, time it, alternating).  Usage:
-    python tools/ab_step.py autograd_nodes.OVERLAP_VGG [rounds [valueA valueB]]      (values: Python literals, default True False)"""
+    python tools/ab_step.py autograd_nodes.OVERLAP_VGG [rounds [valueA valueB]]      (values: Python literals, default True False)
+    S2P_LIB=.../libs2p_hip_diag.so python tools/ab_step.py lib:0 3 0 1      (a run-time switch of the diagnostics library: s2p_diag_set(0, value))"""
 import os, sys, time, importlib
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import torch
@@ -12,8 +13,17 @@ import io, contextlib
 target = sys.argv[1] if len(sys.argv) > 1 else "autograd_nodes.OVERLAP_VGG"
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 vals = (eval(sys.argv[3]), eval(sys.argv[4])) if len(sys.argv) > 4 else (True, False)
-modname, attr = target.rsplit(".", 1)
-mod = importlib.import_module(modname if modname.startswith("s2p_amd") else "s2p_amd.models." + modname)
+if target.startswith("lib:"):
+    import ctypes
+    from s2p_amd import _lib
+
+    class _LibSwitch:                      # setattr(mod, attr, val) -> s2p_diag_set(key, val)
+        def __setattr__(self, k, v):
+            assert ctypes.CDLL(_lib._SO).s2p_diag_set(int(k[1:]), int(v)) == 0
+    mod, attr = _LibSwitch(), "k" + target[4:]
+else:
+    modname, attr = target.rsplit(".", 1)
+    mod = importlib.import_module(modname if modname.startswith("s2p_amd") else "s2p_amd.models." + modname)
 opt = TrainOptions().parse(["--env_type", "cheetah", "--batchSize", "64", "--precision", "bf16", "--gpu_ids", "0",
                             "--checkpoints_dir", "/tmp/ab_ck"], quiet=True)
 with contextlib.redirect_stdout(io.StringIO()):
