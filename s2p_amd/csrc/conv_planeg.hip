@@ -549,13 +549,47 @@ __global__ __launch_bounds__(512) void conv_planeg_kernel(const PlaneGArgs a) {
 // ---- host side --------------------------------------------------------------------------------------------------------------
 namespace {
 struct PgShape { int TY, TX, PB, NPB, S2D; };
-// instantiated shapes: 4x4 stride 1 on planes up to 192 / 64 produced pixels (the 256 -> 512 layers of both scales and their dgrads)
-const PgShape PG_SHAPES[] = {{4, 4, 1, 128, 0}, {4, 4, 3, 256, 0}};
+// instantiated shapes: 4x4 stride 1 on planes up to 64 / 192 produced pixels (the 256 -> 512 layers of both scales and their dgrads);
+// 4x4 stride 2 pad 2 in the parity form (2x2 raster taps) on the same tile sizes (128 -> 256 of both scales, 64 -> 128 of the coarser)
+const PgShape PG_SHAPES[] = {{4, 4, 1, 128, 0}, {4, 4, 3, 256, 0}, {2, 2, 1, 128, 1}, {2, 2, 3, 256, 1}};
 }  // namespace
+
+static bool pg_pick_shape(PlaneGArgs& a, int TY, int TX, int s2d) {
+  const int HW = a.Ho * a.Wo;
+  const int last = (a.Ho - 1 + TY - 1) * a.WP + (a.Wo - 1 + TX - 1);              // last raster position any tap reads
+  a.shape = -1;
+  for (int i = 0; i < (int)(sizeof(PG_SHAPES) / sizeof(PG_SHAPES[0])); ++i) {     // (ordered by tile size: the smallest that fits)
+    const PgShape& s = PG_SHAPES[i];
+    if (s.TY == TY && s.TX == TX && s.S2D == s2d && HW <= 4 * s.PB * 16 && last < s.NPB) { a.shape = i; break; }
+  }
+  // a plane much smaller than the tile wastes the MFMAs: leave those to the generic kernels
+  return a.shape >= 0 && 2 * HW > 4 * PG_SHAPES[a.shape].PB * 16;
+}
 
 bool s2p_conv_planeg_setup(const PlaneGProblem& p, PlaneGArgs& a) {
   if (p.Cin % 64 || p.Cout % 64 || p.Cst != p.Cout || p.x_pitch % 8 || p.y_pitch % 8) return false;
-  if (p.istride != 1) return false;                            // (parity form: not built yet)
+  if (p.Ho < 1 || p.Wo < 1) return false;
+  if (p.istride == 2) {
+    // 4x4 stride 2 pad 2: in(2 y + dy, 2 x + dx), dy = 2 (a - 1) + py in [-2, 1] -> parity sub-plane (py, px), raster tap (a, b) of a 2x2
+    // stride-1 correlation with one row / column of padding in front
+    if (p.T != 16) return false;
+    for (int t = 0; t < 16; ++t) a.wt[t] = -1;
+    for (int t = 0; t < 16; ++t) {
+      const int dy = (int)(signed char)(p.tap[t] & 0xff), dx = (int)(signed char)((p.tap[t] >> 8) & 0xff);
+      if (dy < -2 || dy > 1 || dx < -2 || dx > 1) return false;
+      const int py = dy & 1, px = dx & 1, ra = (dy + 2) >> 1, rb = (dx + 2) >> 1;
+      const int k = (py * 2 + px) * 4 + ra * 2 + rb;
+      if (a.wt[k] >= 0) return false;
+      a.wt[k] = p.tap[t] >> 16;
+    }
+    a.H = p.Hi; a.W = p.Wi; a.Hs = (p.Hi + 1) / 2; a.Ws = (p.Wi + 1) / 2; a.Ho = p.Ho; a.Wo = p.Wo;
+    if (p.Ho != p.Hi / 2 + 1 || p.Wo != p.Wi / 2 + 1) return false;
+    a.PT = 1; a.PL = 1;
+    const int PR = p.Wo - a.Ws > 0 ? p.Wo - a.Ws : 0;
+    a.WP = a.Ws + (PR > 1 ? PR : 1);
+    return pg_pick_shape(a, 2, 2, 1);
+  }
+  if (p.istride != 1) return false;
   if (p.T < 1 || p.T > 16) return false;
   int dy0 = 127, dy1 = -127, dx0 = 127, dx1 = -127;
   for (int t = 0; t < p.T; ++t) {
@@ -576,17 +610,8 @@ bool s2p_conv_planeg_setup(const PlaneGProblem& p, PlaneGArgs& a) {
   // columns / rows a tap reads beyond the gathered grid's last pixel; the raster row is W real columns + max(left pad, right
   // overhang) zero columns, which serve as the right pad of a row AND the left pad of the next one
   const int PR = p.Wo - p.Wi + dx1 > 0 ? p.Wo - p.Wi + dx1 : 0;
-  if (p.Ho < 1 || p.Wo < 1) return false;
   a.WP = p.Wi + (a.PL > PR ? a.PL : PR);
-  const int HW = p.Ho * p.Wo;
-  const int last = (p.Ho - 1 + TY - 1) * a.WP + (p.Wo - 1 + TX - 1);              // last raster position any tap reads
-  a.shape = -1;
-  for (int i = 0; i < (int)(sizeof(PG_SHAPES) / sizeof(PG_SHAPES[0])); ++i) {     // (ordered by tile size: the smallest that fits)
-    const PgShape& s = PG_SHAPES[i];
-    if (s.TY == TY && s.TX == TX && !s.S2D && HW <= 4 * s.PB * 16 && last < s.NPB) { a.shape = i; break; }
-  }
-  // a plane much smaller than the tile wastes the MFMAs: leave those to the generic kernels
-  return a.shape >= 0 && 2 * HW > 4 * PG_SHAPES[a.shape].PB * 16;
+  return pg_pick_shape(a, TY, TX, 0);
 }
 
 template <int TY, int TX, int PB, int NPB, bool S2D>
@@ -603,6 +628,8 @@ int s2p_conv_planeg_launch(PlaneGArgs& a, int groups, hipStream_t st) {
   dim3 grid(a.N * a.nco, groups);
   if (a.shape == 0) pg_launch_shape<4, 4, 1, 128, false>(a, grid, st);
   else if (a.shape == 1) pg_launch_shape<4, 4, 3, 256, false>(a, grid, st);
+  else if (a.shape == 2) pg_launch_shape<2, 2, 1, 128, true>(a, grid, st);
+  else if (a.shape == 3) pg_launch_shape<2, 2, 3, 256, true>(a, grid, st);
   else S2P_FAIL(-1, "conv_planeg: no kernel instantiated for this shape (s2p_conv_planeg_setup decides)");
   S2P_CHECK_LAUNCH("conv_planeg_kernel");
   return 0;

@@ -877,6 +877,44 @@ def test_conv_planeg_4x4_stride1(hip_device, shape):
         assert rel_err(dxn.float().cpu(), dx2.float().cpu().double()) < 1e-2
 
 
+@pytest.mark.parametrize("shape", [
+    (8, 128, 256, 22, 22),      # PatchGAN 128 -> 256 4x4 stride 2 pad 2, finer scale: 22x22 -> 12x12 (four 11x11 parity sub-planes)
+    (3, 64, 128, 22, 22),       # 64 -> 128 of the coarser scale (two 32-channel groups per parity), N % 8 != 0
+    (5, 128, 256, 12, 12),      # 128 -> 256 of the coarser scale: 12x12 -> 7x7, one pixel block per wave
+    (2, 64, 64, 21, 23),        # odd sizes: the parity sub-planes differ in size (11 / 10 rows, 12 / 11 columns)
+    (64, 128, 256, 22, 22),     # the production batch, references on 4 samples
+])
+def test_conv_planeg_4x4_stride2(hip_device, shape):
+    """The generalised plane-resident kernel in its PARITY form (csrc/conv_planeg.hip): a 4x4 stride-2 pad-2 convolution as a 2x2
+    stride-1 convolution over the four parity sub-planes of the input, the space-to-depth done by the LDS-DMA source addresses.
+    Forward, plain and with InstanceNorm + LeakyReLU in the epilogue (s2p_conv2d_fwd_mat), against float64."""
+    import ctypes
+    from s2p_amd import _lib
+    dev = hip_device
+    dtype = torch.bfloat16
+    N, cin, cout, H, W = shape
+    pick = list(range(N)) if N <= 8 else [0, 21, 42, 63]
+    g = torch.Generator().manual_seed(29)
+    r = lambda *sh: torch.randn(*sh, generator=g).bfloat16().float()      # noqa: E731
+    x, w, b = r(N, cin, H, W), r(cout, cin, 4, 4) / math.sqrt(cin * 16), torch.randn(cout, generator=g)
+    geom = ops.ConvGeom(cin, cout, 4, 2, 2)
+    Ho, Wo = geom.out_hw(H, W)
+    d = geom.desc(dtype, N, H, W, cin, cin, cout)
+    assert _lib.lib().s2p_conv2d_mat_is_fused(ctypes.byref(d), 0, 0) == 1
+    xd, wf = nhwc(x, cin, dtype, dev), pack_fwd(w, cin, dtype, dev)
+    y = ops.conv_fwd(geom, xd, wf, b.to(dev), cin, act=ACT_LRELU, slope=0.2)
+    y_ref = F.conv2d(x[pick].double(), w.double(), b.double(), stride=2, padding=2)
+    assert tuple(y.shape[1:3]) == (Ho, Wo) == tuple(y_ref.shape[2:])
+    assert rel_err(nchw(y, cout)[pick], F.leaky_relu(y_ref, 0.2)) < TOL[dtype]
+    c, f, stats = ops.conv_fwd_mat(geom, xd, wf, None, cin, None, 0, None, 0, act=ACT_LRELU, slope=0.2)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(c, cout)[pick], y_ref - b.double()[None, :, None, None]) < TOL[dtype]
+    cs = nchw(c, cout)[pick].double()
+    assert rel_err(nchw(f, cout)[pick], F.leaky_relu(F.instance_norm(cs, eps=1e-5), 0.2)) < 6e-3
+    mom = stats[4:4 + N * cout * 2].view(N, cout, 2).cpu()[pick].double()
+    assert rel_err(mom[..., 0], cs.mean((2, 3))) < 1e-4
+
+
 @pytest.mark.parametrize("residual", [False, True])
 def test_plane_kernels_production_shape(hip_device, residual):
     """The production shapes of the timed workload (missing #2), at full size, against float64 on samples
