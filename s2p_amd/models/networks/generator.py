@@ -30,6 +30,9 @@ FUSE_NORM_FWD = True     # ResBlk forward: InstanceNorm + MAT + LeakyReLU in the
 FUSE_NORM_BWD = True     # ResBlk backward: each MAT norm's backward in the epilogue of the following dgrad (s2p_conv2d_dgrad_mat)
 GB_GROUP_MAJOR = True    # the 12 gamma|beta planes (and their gradients) as [12][N][h][w][2C] (1-KB rows, one tensor per norm) instead of
                          # channel slices of one [N][h][w][12*2C] tensor (12-KB rows): the fused conv + norm tails read them 10 % faster
+GB_WGRAD_CHUNKED = True  # with the data-parallel exchange on: the gamma/beta heads' weight gradients follow the ResBlk batches (4 norms per batch)
+                         # instead of one 12-group launch at the end, so 2/3 of the gradient is in flight before the last weight-gradient launch.
+                         # On one rank the single launch stays: same-box A/B 8.907 (one launch) vs 8.947 ms/step (three)
 COND_SIDE = True         # backward of the image-conditioning branch on its own stream, concurrent with the encoder backward
 
 
@@ -119,6 +122,29 @@ class S2PGenerator(BaseNetwork):
             if e["param"] is self._early_first:
                 return e["offset"]
         raise RuntimeError("network not finalized")
+
+    def early_buckets(self):
+        """The early-complete tail of the flat gradient as BUCKETS that become final one after the other during the backward
+        (data-parallel exchange, Pix2PixTrainer): bucket j holds what the j-th batch of deferred weight gradients completes --
+        the convs of WGRAD_CHUNK_BLOCKS ResBlks and the gamma/beta heads of their norms; the first bucket also holds the up / output
+        convs, whose gradients are final from the start of the backward.  Each bucket is a list of (offset, numel) ranges."""
+        off = {id(e["param"]): (e["offset"], e["numel"]) for e in self.store.entries}
+        end = self.store.numel
+        norms = self._norms()
+        nb, step = self.n_blocks, (WGRAD_CHUNK_BLOCKS if WGRAD_CHUNK_BLOCKS > 0 else self.n_blocks)
+        buckets = []
+        for hi in range(nb - 1, -1, -step):
+            lo = max(hi - step + 1, 0)
+            n0, n1 = norms[2 * lo], norms[2 * hi + 1]
+            r = [(off[id(n0.mlp_gamma.weight)][0], sum(off[id(n1.mlp_beta.weight)]) - off[id(n0.mlp_gamma.weight)][0]),
+                 (off[id(n0.mlp_gamma.bias)][0], sum(off[id(n1.mlp_beta.bias)]) - off[id(n0.mlp_gamma.bias)][0])]
+            c0 = off[id(self.blocks[lo].conv_0.weight)][0]
+            c1 = end if hi == nb - 1 else sum(off[id(self.blocks[hi].conv_1.bias)])
+            r.append((c0, c1 - c0))
+            buckets.append(r)
+        assert min(o for b in buckets for o, _ in b) == self.early_grad_offset
+        assert sum(n for b in buckets for _, n in b) == end - self.early_grad_offset
+        return buckets
 
     # ---- flat layout + packed operands ---------------------------------------------------------------------
     def _norms(self):
@@ -360,6 +386,24 @@ class S2PGenerator(BaseNetwork):
                 if extra is not None:
                     extra()
 
+        actv, seg = ctx["actv"], ctx["seg"]
+        if ws is not None:
+            actv.record_stream(ws); dgb_all.record_stream(ws)
+        hook = self.on_early_grads
+        chunked = GB_WGRAD_CHUNKED and hook is not None and ws is not None and WGRAD_CHUNK_BLOCKS > 0 and gb_all.dim() == 5
+        n_buckets = len(self.early_buckets()) if (hook is not None and chunked) else 1
+        pending = []              # batches issued on the side stream whose bucket has not been handed to the exchange yet
+
+        def gb_wgrad(b_lo, b_hi):             # the gamma/beta heads of the norms of blocks b_lo..b_hi (groups 2 b_lo .. 2 b_hi + 1)
+            return lambda: L["gb"].wgrad(actv, dgb_all, groups=(2 * b_lo, 2 * b_hi + 2))
+
+        def hand_over():
+            """The previous batch ran under the blocks just finished: re-join the side stream and start that bucket's exchange."""
+            nonlocal ws
+            if hook is not None and chunked and pending:
+                main.wait_stream(ws)
+                hook(pending.pop(0))
+
         wjobs = []
         for k, b in enumerate(reversed(range(self.n_blocks))):
             x, sA, nA, c0, sB, nB = ctx["blocks"][b]
@@ -373,36 +417,37 @@ class S2PGenerator(BaseNetwork):
                 d_c0 = L[f"b{b}c1"].dgrad_mat(dx, c0, sB, *G1, st_all, o1, ACT_LRELU, LRELU, *D1, dst_all, o1)
                 wjobs.append((L[f"b{b}c0"], nA, d_c0))
                 dx = L[f"b{b}c0"].dgrad_mat(d_c0, x, sA, *G0, st_all, o0, ACT_LRELU, LRELU, *D0, dst_all, o0, res=dx)
-                if ws is not None and WGRAD_CHUNK_BLOCKS > 0 and (k + 1) % WGRAD_CHUNK_BLOCKS == 0 and k + 1 < self.n_blocks:
-                    side_wgrads(wjobs)
-                    wjobs = []
-                continue
-            wjobs.append((L[f"b{b}c1"], nB, dx))
-            d_nB = L[f"b{b}c1"].dgrad(dx, nB.shape)
-            d_c0 = ops.in_bwd(d_nB, c0, C, sB, *G1, st_all, o1, ACT_LRELU, LRELU, *D1, dst_all, o1)
-            wjobs.append((L[f"b{b}c0"], nA, d_c0))
-            d_nA = L[f"b{b}c0"].dgrad(d_c0, nA.shape)
-            if FUSE_SKIP_ADD:       # the skip-connection gradient dx is added in the same launch: no separate add pass
-                dx = ops.in_bwd(d_nA, x, C, sA, *G0, st_all, o0, ACT_LRELU, LRELU, *D0, dst_all, o0, res=dx)
             else:
-                d_xb = ops.in_bwd(d_nA, x, C, sA, *G0, st_all, o0, ACT_LRELU, LRELU, *D0, dst_all, o0)
-                dx = ops.add(dx, d_xb, out=d_xb)
+                wjobs.append((L[f"b{b}c1"], nB, dx))
+                d_nB = L[f"b{b}c1"].dgrad(dx, nB.shape)
+                d_c0 = ops.in_bwd(d_nB, c0, C, sB, *G1, st_all, o1, ACT_LRELU, LRELU, *D1, dst_all, o1)
+                wjobs.append((L[f"b{b}c0"], nA, d_c0))
+                d_nA = L[f"b{b}c0"].dgrad(d_c0, nA.shape)
+                if FUSE_SKIP_ADD:       # the skip-connection gradient dx is added in the same launch: no separate add pass
+                    dx = ops.in_bwd(d_nA, x, C, sA, *G0, st_all, o0, ACT_LRELU, LRELU, *D0, dst_all, o0, res=dx)
+                else:
+                    d_xb = ops.in_bwd(d_nA, x, C, sA, *G0, st_all, o0, ACT_LRELU, LRELU, *D0, dst_all, o0)
+                    dx = ops.add(dx, d_xb, out=d_xb)
             if ws is not None and WGRAD_CHUNK_BLOCKS > 0 and (k + 1) % WGRAD_CHUNK_BLOCKS == 0 and k + 1 < self.n_blocks:
-                side_wgrads(wjobs)
+                hand_over()
+                side_wgrads(wjobs, gb_wgrad(b, b + WGRAD_CHUNK_BLOCKS - 1) if chunked else None)
+                pending.append((k + 1) // WGRAD_CHUNK_BLOCKS - 1)       # this batch completes bucket 0, 1, ...
                 wjobs = []
-        actv, seg = ctx["actv"], ctx["seg"]
-        if ws is not None:
-            actv.record_stream(ws); dgb_all.record_stream(ws)
         # the rest of the block convs' weight gradients + the image-conditioning branch's (batched)
-        side_wgrads(wjobs, lambda: L["gb"].wgrad(actv, dgb_all))
+        hand_over()
+        if chunked:
+            rest = len(wjobs) // 2                                       # blocks still in wjobs: 0 .. rest - 1
+            side_wgrads(wjobs, gb_wgrad(0, rest - 1) if rest > 0 else None)
+        else:
+            side_wgrads(wjobs, lambda: L["gb"].wgrad(actv, dgb_all))
         # every gradient of the flat buffer's tail [early_grad_offset, end) is final once these are done (data-parallel hook:
-        # the trainer starts that bucket's all-reduce here, under the rest of this backward; a graph segment ends at the
+        # the trainer starts the last bucket's all-reduce here, under the rest of this backward; a graph segment ends at the
         # hook, so the side stream re-joins first)
-        if self.on_early_grads is not None:
+        if hook is not None:
             if ws is not None:
                 main.wait_stream(ws)
                 ws = None
-            self.on_early_grads()
+            hook(n_buckets - 1 if chunked else None)
         # backward of the image-conditioning branch on its side stream, concurrent with the encoder backward below
         cs = self._cond_stream() if (COND_SIDE and not ops.SERIALIZE) else main
         if cs is not main:

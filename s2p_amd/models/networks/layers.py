@@ -59,8 +59,9 @@ class ConvLayer:
         return ops.conv_dgrad_mat(self.geom, dy, self.pk.w_bwd, xn, self.cin_pad(dy.dtype), stats, gb, gb_off, gb_st, st_off,
                                   act, slope, dgb, dgb_off, dgb_st, dst_off, res=res, aux=aux)
 
-    def wgrad(self, x, dy):
-        """Accumulate weight (and bias) gradients straight into the flat grad buffer."""
+    def wgrad(self, x, dy, groups=None):
+        """Accumulate weight (and bias) gradients straight into the flat grad buffer.  groups=(g0, g1): only the groups g0 .. g1 - 1
+        of a grouped conv (the generator's gamma/beta heads in batches that follow the ResBlk backward)."""
         g = self.geom
         if g.groups > 1 and x.dtype == torch.bfloat16 and g.k == 3 and g.stride == 1 and g.pad == 1 and not g.transposed \
                 and g.groups <= 16 and g.cin % 64 == 0 and g.cout % 64 == 0:
@@ -68,13 +69,15 @@ class ConvLayer:
             one = ConvGeom(g.cin, g.cout, 3, 1, 1)
             gw = self.pk.gw.view(g.groups, -1)
             gb = self.pk.gb.view(g.groups, -1) if self.pk.gb is not None else None
+            sel = range(g.groups) if groups is None else range(groups[0], groups[1])
             if dy.dim() == 5:       # group-major dy: one whole tensor per group
-                jobs = [(x, i * g.x_gstride, dy[i], 0, gw[i], gb[i] if gb is not None else None) for i in range(g.groups)]
+                jobs = [(x, i * g.x_gstride, dy[i], 0, gw[i], gb[i] if gb is not None else None) for i in sel]
             else:
-                jobs = [(x, i * g.x_gstride, dy, i * g.y_gstride, gw[i], gb[i] if gb is not None else None)
-                        for i in range(g.groups)]
+                jobs = [(x, i * g.x_gstride, dy, i * g.y_gstride, gw[i], gb[i] if gb is not None else None) for i in sel]
             ops.conv_wgrad_batched(one, jobs, g.cin, self.cin_real, self.cout_real)
             return
+        if groups is not None:
+            raise RuntimeError("a group range is only wired for the batched slab weight-gradient path")
         if dy.dim() == 5:
             raise RuntimeError("group-major dY is only wired for the batched slab weight-gradient path (bf16, 3x3, 64-channel multiples)")
         if g.groups == 1 and g.cout == 1 and x.dtype == torch.bfloat16 and g.stride == 1 and not g.transposed and not g.reflect:

@@ -6,9 +6,11 @@ followed by one fused Adam launch.  No DataParallel wrapper, no per-tensor bucke
 collectives run on a communication stream and are hidden under compute:
 
   * G step: the flat G buffer is laid out so that the 97 % of the gradient that is final once the ResBlk chain and the
-    deferred weight gradients are done is one contiguous tail; its all-reduce starts there (a hook inside the generator's
-    backward) and runs under the rest of the backward (gamma/beta dgrad, shared conv, encoder, state path); only the
-    small head of the buffer is reduced after the backward;
+    deferred weight gradients are done is one contiguous tail; it is exchanged in THREE buckets that follow the batches of
+    deferred weight gradients (two ResBlks + the gamma/beta heads of their four norms each: 20 / 19 / 19 MB): a bucket's
+    all-reduce starts from a hook inside the generator's backward as soon as its batch has finished, so two thirds of
+    the payload are in flight before the last weight-gradient launch and the last third runs under the rest of the backward
+    (gamma/beta dgrad, shared conv, encoder, state path); only the small head of the buffer is reduced after the backward;
   * D step: all-reduce + Adam + weight repack of D run entirely on the communication stream, under the NEXT step's
     generator forward; the next G step waits for them right before its first use of D (a hook in the G-loss node).
 
@@ -33,6 +35,7 @@ class Pix2PixTrainer:
         self.seg = None
         self._eD = None                 # event: D's all-reduce + Adam + repack of the previous step are done
         self._eD_waited = True          # ... and whether the main stream has waited for it since it was recorded
+        self._buckets = None            # S2PGenerator.early_buckets(), resolved at the first exchange
         self.comm_events = None         # a list: (event, event) pairs around every wait of the compute stream for the exchange
         self.dp = parallel.DataParallelGroup.from_env()
         if opt.isTrain:
@@ -76,10 +79,22 @@ class Pix2PixTrainer:
         self._cut(act)
         self._eD_waited = True
 
-    def _allreduce_G_tail(self):
+    def _allreduce_G_tail(self, bucket=None):
+        """Hook of the generator's backward: `bucket` (see S2PGenerator.early_buckets) of the flat gradient's early-complete tail is
+        final -- start its all-reduce on the communication stream, under the rest of the backward.  bucket None: the whole tail."""
         net = self.pix2pix_model.netG
-        tail = net.store.grad[net.early_grad_offset:]
-        self._cut(lambda: self.dp.all_reduce_async(tail))
+        g = net.store.grad
+        if bucket is None:
+            parts = [g[net.early_grad_offset:]]
+        else:
+            if self._buckets is None:
+                self._buckets = net.early_buckets()
+            parts = [g[o:o + n] for o, n in self._buckets[bucket]]
+
+        def act():
+            for t in parts:
+                self.dp.all_reduce_async(t)
+        self._cut(act)
 
     def _finish_G_exchange(self):
         net = self.pix2pix_model.netG

@@ -128,6 +128,15 @@ def test_flat_param_store_layout_on_cpu():
     assert torch.allclose(netG.out.bias, before["out.bias"] + 1.0)
     ck = netG.export_state_dict()
     assert all(v.is_contiguous() for v in ck.values())
+    # data-parallel exchange buckets: they partition the early-complete tail of the flat gradient, the first (the one the backward
+    # completes first) ends at the end of the buffer, and at least 2/3 of the tail is in the buckets before the last one
+    bk = netG.early_buckets()
+    assert len(bk) == 3 and all(len(r) == 3 for r in bk)
+    spans = sorted((o, o + n) for r in bk for o, n in r)
+    assert spans[0][0] == netG.early_grad_offset and spans[-1][1] == st.numel
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])) and sum(b - a for a, b in spans) == st.numel - netG.early_grad_offset
+    assert max(o + n for o, n in bk[0]) == st.numel
+    assert sum(n for r in bk[:-1] for _, n in r) >= 0.66 * (st.numel - netG.early_grad_offset)
 
 
 def test_dataset_and_checkpoint_naming(tmp_path):
