@@ -62,6 +62,7 @@ class BaseNetwork(nn.Module):
         self.compute_dtype = compute_dtype
         self._declare_packs(compute_dtype)
         self.store.finalize(device)
+        self.store.param_names = {id(p): n for n, p in self.named_parameters()}     # part of the checkpointed layout signature
         self.finalized = True
         return self
 

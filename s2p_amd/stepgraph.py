@@ -17,8 +17,8 @@ Outside `capture` (eager mode, or `enabled=False`) `cut(action)` simply calls `a
 serves eager training, warm-up and capture.  All segments share one memory pool: tensors produced in one segment
 and consumed in a later one (activations saved for backward, gradient buffers) keep their addresses across replays.
 """
+import ctypes
 import gc
-import warnings
 
 import torch
 
@@ -60,8 +60,21 @@ class StepGraph:
         self._begin_segment()
 
     # ---- capture / replay ----------------------------------------------------------------------------------
+    @staticmethod
+    def _node_count(g):
+        """Nodes of a captured (not yet instantiated) graph, asked from the HIP runtime; None when it cannot be asked."""
+        try:
+            hip = ctypes.CDLL("libamdhip64.so")
+            n = ctypes.c_size_t(0)
+            rc = hip.hipGraphGetNodes(ctypes.c_void_p(g.raw_cuda_graph()), None, ctypes.byref(n))
+            return int(n.value) if rc == 0 else None
+        except Exception:
+            return None
+
     def _begin_segment(self):
-        g = torch.cuda.CUDAGraph()
+        # keep_graph: capture_end leaves the hipGraph un-instantiated, so that an empty segment can be recognised (and dropped)
+        # by COUNTING ITS NODES -- no warning text to parse, no process-global warning state touched from autograd's worker thread
+        g = torch.cuda.CUDAGraph(keep_graph=True)
         # "relaxed": a cut may come from autograd's worker thread (a hook inside a backward), i.e. the capture is ended /
         # begun by a different thread than the one that started it, and RCCL's watchdog thread polls events meanwhile
         g.capture_begin(pool=self._pool, capture_error_mode="relaxed")
@@ -69,15 +82,11 @@ class StepGraph:
 
     def _end_segment(self):
         # two cuts back to back (or a cut as the last thing of the step) leave a segment without a single node: it is dropped,
-        # so a replay does not pay a graph launch + host round trip for nothing
-        with warnings.catch_warnings(record=True) as w:
-            warnings.simplefilter("always")
-            self._cur.capture_end()
-        empty = any("graph is empty" in str(x.message).lower() for x in w)
-        for x in w:
-            if "graph is empty" not in str(x.message).lower():
-                warnings.warn_explicit(x.message, x.category, x.filename, x.lineno)
-        if not empty:
+        # so a replay does not pay a graph launch + host round trip for nothing.  A segment whose node count cannot be read is kept.
+        self._cur.capture_end()
+        n = self._node_count(self._cur)
+        if n is None or n > 0:
+            self._cur.instantiate()
             self.seq.append(("graph", self._cur))
         self._cur = None
 

@@ -128,6 +128,15 @@ def test_flat_param_store_layout_on_cpu():
     assert torch.allclose(netG.out.bias, before["out.bias"] + 1.0)
     ck = netG.export_state_dict()
     assert all(v.is_contiguous() for v in ck.values())
+    # the checkpointed layout signature names every entry: swapping two same-shaped parameters changes it, and an
+    # optimizer state without a signature is refused instead of being applied on numel alone
+    names = {id(p): n for n, p in netG.named_parameters()}
+    sig = st.layout_signature(names)
+    a, b = netG.blocks[0].conv_0.weight, netG.blocks[1].conv_0.weight
+    swapped = dict(names); swapped[id(a)], swapped[id(b)] = names[id(b)], names[id(a)]
+    assert st.layout_signature(names) == sig and st.layout_signature(swapped) != sig and len(sig) == 16
+    with pytest.raises(RuntimeError, match="no flat-layout signature"):
+        st.load_optimizer_state(dict(step=1, m=torch.zeros(st.numel), v=torch.zeros(st.numel)))
     # data-parallel exchange buckets: they partition the early-complete tail of the flat gradient, the first (the one the backward
     # completes first) ends at the end of the buffer, and at least 2/3 of the tail is in the buckets before the last one
     bk = netG.early_buckets()
