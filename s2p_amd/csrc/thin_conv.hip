@@ -441,6 +441,138 @@ __global__ __launch_bounds__(512) void thin_tiled_wgrad_kernel(const TileArgs a)
   }
 }
 
+// ---- 7x7 stride-1 pad-3 weight gradient with Cin = 64 and Cout <= 4 (the generator's output conv), row-streaming form (round 4) ------
+// The tiled kernel above re-reads x 2.4 times (16x8 tiles with a 6-pixel halo), loads each halo synchronously and spends an MFMA
+// per (tap, 16 channels) with 3 of its 16 rows used: 125 us, alone on the chip at the start of the generator's backward.  Here
+//   * a workgroup owns a BAND of 21 output rows of one image over the full width and streams the input rows once through an
+//     8-row LDS ring (1.29x instead of 2.4x; the next row's global loads are in flight while the current one is computed);
+//   * the MFMA's thin side carries (kx, co) -- 21 of 32 rows used instead of 3 of 16: for a fixed ky,
+//         dW[co][ky][kx][ci] = sum_{p'} dY[row][p' - kx][co] * X[row + ky][p'][ci]
+//     so A[m = (kx, co)][k = p'] is dY shifted by kx (seven shifted planar copies of each dY row are kept in LDS, so every
+//     fragment is one aligned 16-byte read) and B[k = p'][ci] is the halo row through ds_read_b64_tr_b16, one k-chunk = 32 columns;
+//   * wave (m tile, 16-channel group) keeps the accumulators of all seven ky: an input row is read from LDS once and used by up
+//     to seven output rows.
+constexpr int R7_XC = 96, R7_XS = 144, R7_BAND = 21, R7_MR = 24;
+struct Rows7Args {
+  const __bf16* x; const __bf16* dy; float* dw; float* part;
+  int N, H, W, x_pitch, y_pitch, Cout, cin_real, reflect, nbands;
+};
+
+__global__ __launch_bounds__(512) void thin_rows7_wgrad_kernel(const Rows7Args a) {
+  __shared__ __attribute__((aligned(16))) char xring[8 * R7_XC * R7_XS];
+  __shared__ __attribute__((aligned(16))) __bf16 dyc[8 * R7_MR * R7_XC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, kg = lane >> 4;
+  const int q = (lane >> 2) & 3, p = lane & 3;           // transposed-read lane roles inside the 16-lane group
+  const int cg = wave & 3, mt = wave >> 2;
+  const int n = blockIdx.x / a.nbands, band = blockIdx.x - n * a.nbands;
+  const int r0 = band * R7_BAND;
+  const int nrows = a.H - r0 < R7_BAND ? a.H - r0 : R7_BAND;
+  const int M = 7 * a.Cout;
+  for (int i = tid; i < 8 * R7_XC * R7_XS / 16; i += 512) ((u32x4*)xring)[i] = (u32x4){0u, 0u, 0u, 0u};
+  for (int i = tid; i < 8 * R7_MR * R7_XC * 2 / 16; i += 512) ((u32x4*)dyc)[i] = (u32x4){0u, 0u, 0u, 0u};
+  f32x4_t acc[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) acc[k] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int ncols = a.W + 6;                             // halo columns: image columns -3 .. W + 2
+  u32x4 xv[2], dv;
+  auto load_row = [&](int h) {                           // halo row h of x and output row h of dY -> registers
+    int iy = r0 - 3 + h;
+    bool rok = true;
+    if (a.reflect) { iy = iy < 0 ? -iy : (iy >= a.H ? 2 * a.H - 2 - iy : iy); iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy); }
+    else rok = iy >= 0 && iy < a.H;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 512 * i, col = idx >> 3, ch = idx & 7;
+      xv[i] = (u32x4){0u, 0u, 0u, 0u};
+      if (col < ncols) {
+        int ix = col - 3;
+        bool ok = rok;
+        if (a.reflect) { ix = ix < 0 ? -ix : (ix >= a.W ? 2 * a.W - 2 - ix : ix); ix = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix); }
+        else ok = ok && ix >= 0 && ix < a.W;
+        if (ok) xv[i] = *(const u32x4*)(a.x + (((size_t)n * a.H + iy) * a.W + ix) * a.x_pitch + ch * 8);
+      }
+    }
+    dv = (u32x4){0u, 0u, 0u, 0u};
+    if (tid < a.W && h < nrows) dv = *(const u32x4*)(a.dy + (((size_t)n * a.H + r0 + h) * a.W + tid) * a.y_pitch);
+  };
+  auto store_row = [&](int h) {
+    const int slot = h & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 512 * i, col = idx >> 3, ch = idx & 7;
+      if (col < ncols) *(u32x4*)(xring + (slot * R7_XC + col) * R7_XS + ch * 16) = xv[i];
+    }
+    if (tid < a.W && h < nrows) {
+      for (int co = 0; co < a.Cout; ++co) {
+        const unsigned short v = (unsigned short)((dv[co >> 1] >> ((co & 1) * 16)) & 0xffff);
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) *(unsigned short*)(dyc + ((slot * R7_MR + kx * a.Cout + co) * R7_XC + tid + kx)) = v;
+      }
+    }
+  };
+  __syncthreads();                                       // the rings are zero
+  load_row(0);
+  store_row(0);
+  __syncthreads();
+  const int nsteps = nrows + 6;
+  const int m = 16 * mt + l15;
+  const bf16x8 zero8 = {};
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  for (int h = 0; h < nsteps; ++h) {
+    if (h + 1 < nsteps) load_row(h + 1);
+    // B fragments of halo row h: [k = 32 c + 8 kg + j][ci = 16 cg + l15]
+    bf16x8 bfr[3];
+    const char* xrow = xring + ((h & 7) * R7_XC) * R7_XS;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const char* base = xrow + (32 * c + 8 * kg + q) * R7_XS + (cg * 16 + 4 * p) * 2;
+      s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+      s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * R7_XS));
+      s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      bfr[c] = __builtin_bit_cast(bf16x8, v);
+    }
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) {
+      const int r = h - ky;                              // output row (in the band) that pairs with halo row h under tap row ky
+      if (r >= 0 && r < nrows) {                         // workgroup-uniform
+        const __bf16* drow = dyc + ((r & 7) * R7_MR + m) * R7_XC + 8 * kg;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          bf16x8 afr = zero8;
+          if (m < M) afr = *(const bf16x8*)(drow + 32 * c);
+          acc[ky] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[c], acc[ky], 0, 0, 0);
+        }
+      }
+    }
+    if (h + 1 < nsteps) store_row(h + 1);                // slot (h + 1) & 7 held row h - 7: nobody reads it any more
+    __syncthreads();
+  }
+  // D: col = lane & 15 (ci within the group), row = (lane >> 4) * 4 + reg -> m = (kx, co)
+  const int ci = cg * 16 + l15;
+  if (ci < a.cin_real) {
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int mm = 16 * mt + 4 * kg + e;
+        if (mm < M) {
+          const int kx = mm / a.Cout, co = mm - kx * a.Cout;
+          const size_t o = ((size_t)co * 49 + ky * 7 + kx) * a.cin_real + ci;
+          if (a.part) a.part[(size_t)blockIdx.x * ((size_t)a.Cout * 49 * a.cin_real) + o] = acc[ky][e];
+          else atomicAdd(a.dw + o, acc[ky][e]);
+        }
+      }
+  }
+}
+
+static bool rows7_applicable(const s2p_conv_desc* d) {
+  return d->dtype == S2P_BF16 && d->groups == 1 && !d->transposed && d->Cout <= 4 && d->stride == 1 && d->KH == 7 && d->KW == 7 &&
+         d->pad == 3 && d->Cin == 64 && d->x_pitch == 64 && d->y_pitch == 8 && d->Ho == d->H && d->Wo == d->W && d->W + 6 <= R7_XC &&
+         d->W <= 512 && d->H >= 7;
+}
+static int rows7_blocks(const s2p_conv_desc* d) { return d->N * cdiv(d->H, R7_BAND); }
+
 static bool tiled_applicable(const s2p_conv_desc* d) {
   if (!(d->dtype == S2P_BF16 && d->groups == 1 && !d->transposed && d->Cout <= 4 && d->stride == 1 && d->KH == d->KW &&
         d->KH >= 3 && d->KH <= 7 && d->Cin % 32 == 0 && d->Cin <= 128 && d->y_pitch == 8 && d->x_pitch == d->Cin))
@@ -471,10 +603,16 @@ int s2p_thin_tiled_fwd(const s2p_conv_desc* d, const void* x, const void* w, con
   return 0;
 }
 
-static int tiled_wgrad_blocks(const s2p_conv_desc* d) {
+static int tiled_wgrad_blocks(const s2p_conv_desc* d) {      // partial tiles the caller's workspace must hold
   TileArgs a{};
   fill_tile_args(a, d);
-  return a.ntiles < 512 ? a.ntiles : 512;
+  const int tiled = a.ntiles < 512 ? a.ntiles : 512;
+  if (!rows7_applicable(d)) return tiled;
+#ifdef S2P_DIAG_BUILD
+  return rows7_blocks(d) > tiled ? rows7_blocks(d) : tiled;   // the diagnostics build can switch between the two kernels at run time
+#else
+  return rows7_blocks(d);
+#endif
 }
 
 int s2p_thin_tiled_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, int cin_real, void* ws, size_t ws_bytes,
@@ -484,6 +622,18 @@ int s2p_thin_tiled_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, 
   a.x = (const __bf16*)x; a.dy = (const __bf16*)dy; a.dw = dw; a.cin_real = cin_real;
   const size_t need = s2p_thin_wgrad_ws_bytes(d, cin_real);
   a.part = (ws && need > 0 && ws_bytes >= need) ? (float*)ws : nullptr;
+  if (rows7_applicable(d) && !S2P_DIAG_SWITCH(1)) {
+    Rows7Args r{a.x, a.dy, dw, a.part, d->N, d->H, d->W, d->x_pitch, d->y_pitch, d->Cout, cin_real, d->reflect, cdiv(d->H, R7_BAND)};
+    const int blocks = rows7_blocks(d);
+    hipLaunchKernelGGL(thin_rows7_wgrad_kernel, dim3(blocks), dim3(512), 0, st, r);
+    S2P_CHECK_LAUNCH("thin_rows7_wgrad_kernel");
+    if (a.part) {
+      const int n = d->Cout * 49 * cin_real;
+      s2p_partial_reduce(a.part, blocks, n, n, dw, st);
+      S2P_CHECK_LAUNCH("s2p_partial_reduce_kernel(thin rows7 wgrad)");
+    }
+    return 0;
+  }
   const int HW_ = TW + d->KH - 1, HH = TH + d->KH - 1;
   const size_t lds = (size_t)HW_ * HH * (d->Cin * 2 + 16) + 4 * TW * TH * 2;
   const int pairs = d->KH * d->KW * (d->Cin / 16);
