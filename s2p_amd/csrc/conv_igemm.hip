@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
   if (S2P_DIAGV(a) == 3) return;                              // timing ablation: prologue only
   int slab = 0, tap = 0;
   // S2P_DIAG=8 (diagnostic build of the launch, output invalid): stamp shader clock and 100 MHz wall clock around the
-  // main loop; the host tool derives the in-kernel clock and cycles per K step (tools/clock_halo.py)
+  // main loop; the host tool derives the in-kernel clock and cycles per K step (diagnostics build)
   unsigned long long st_c0 = 0, st_r0 = 0;
   if (S2P_DIAGV(a) == 8) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
   for (int kt = 0; kt < nk; ++kt) {

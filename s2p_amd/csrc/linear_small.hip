@@ -131,19 +131,13 @@ __global__ __launch_bounds__(256) void lin_wgrad_kernel(const LinArgs a) {
 }
 
 #ifdef S2P_DIAG_BUILD
-// ---- diagnostics build only: the LDS-staged VALU kernels of rounds 2-3 (S2P_LIN_LDS=1 selects them), kept as the subject of the
-// LDS co-residency repro (tools/repro_lds_modes.sh, tests/tools/repro_lds.py) -------------------------------------------------
-// ---- how the staged tiles are read back from LDS --------------------------------------------------------------------
-// The tiles are padded to an odd pitch (65 / 17 floats) so that column reads spread over the banks; a row then starts
-// 0 / 4 / 8 / 12 bytes off 16-byte alignment depending on row % 4.  hipcc merges the unrolled k-loop's neighbouring loads
-// of such a row into ds_read2_b32 / ds_read2_b64 / ds_read_b128, and on MI355X those MULTI-DWORD reads of rows that are
-// 12 bytes off alignment (lanes 48..63 here) returned wrong data whenever an LDS-DMA kernel (buffer_load ... lds) shared the
-// CU (tests/tools/repro_lds.py with the S2P_LIN_LDS_MODE builds below).  The product build therefore
-// reads every element with lds_ld(): a relaxed atomic load, which the compiler may neither merge nor widen -- exactly one
-// ds_read_b32 per element (tests/test_host_logic.py::test_lds_access_widths checks the ISA), and keeps the odd pitch.
-// Diagnostic builds (build.sh diag -DS2P_LIN_LDS_MODE=n) restore the other forms for the repro:
-//   1: plain loads, pitch 65 (the code as first written)   2: plain loads, pitch 68 (every row 16-byte aligned)
-//   3: plain x-tile loads, lds_ld() for the w tile          4: lds_ld() for the x tile, plain w-tile loads
+// ---- diagnostics build only: the LDS-staged VALU kernels of rounds 2-3 (S2P_LIN_LDS=1 selects them; tools/bench_lin.py times them
+// against the MFMA kernels above).  They are where the co-residency wrong-result hazard was first seen (lanes 48..63, ~1 % of a
+// partial sum, beside an LDS-DMA conv kernel).  Rounds 2-3 read that as an LDS effect of the MERGED reads hipcc formed on the
+// odd-pitch tiles and bisected read forms (S2P_LIN_LDS_MODE 1..4: plain loads at pitch 65 / 68, element-wise lds_ld() on one tile
+// or the other).  Round 4 showed the cause to be PACKED fp32 instructions with an op_sel swizzle: the merged
+// reads only put the operands in adjacent registers, which let the SLP vectoriser pack the FMAs; lds_ld() blocked that.  With the
+// library built without packed fp32 every mode is safe; the modes stay as the record of that bisection.
 #ifndef S2P_LIN_LDS_MODE
 #define S2P_LIN_LDS_MODE 0
 #endif

@@ -97,9 +97,9 @@ __device__ __forceinline__ float act_grad_from_out(float y, int act, float slope
   }
 }
 
-// One LDS element = one ds_read_b32: a relaxed atomic load, which the compiler may neither merge with its neighbours nor widen.
-// For tiles padded to an odd pitch that are read along a row by an unrolled loop: the ds_read2_b32 / ds_read2_b64 / ds_read_b128
-// hipcc merges such reads into returned wrong data beside LDS-DMA kernels on the same CU.
+// One LDS element = one ds_read_b32: a relaxed atomic load, which the compiler may neither merge with its neighbours nor widen
+// (nor feed to the SLP vectoriser as part of a packed pair).  Used by the diagnostics build's LDS-staged linear kernels and the
+// weight-pack kernel's odd-pitch tile.
 __device__ __forceinline__ float lds_ld(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }

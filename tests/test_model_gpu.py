@@ -854,16 +854,15 @@ def test_train_cli_graph_replay_matches_eager(hip_device, tmp_path):
 
 
 def test_small_kernels_are_undisturbed_by_lds_dma_kernels_on_the_same_cus(hip_device, tmp_path):
-    """Regression for a co-residency hazard found on MI355X: while an LDS-DMA conv kernel
-    (`buffer_load ... lds`) runs on another stream and shares CUs with them, the state path's linear kernels returned wrong
-    data in lanes 48..63 for the MERGED (multi-dword) LDS reads hipcc had formed on their weight tile -- ~1 % of a partial sum,
-    every run -- which made the state-MLP gradients of the overlapped train step differ by 1-10 % from run to run.  The
-    S2P_LIN_LDS_MODE builds of linear_small.hip (tools/repro_lds_modes.sh) show that it is the merged reads of the tile whose
-    address is uniform over each 16-lane group, at any alignment, and that element-wise (relaxed-atomic) loads are immune; the
-    kernels now use those (tests/test_host_logic.py::test_lds_access_widths pins the ISA).
-    Here every non-DMA LDS-using kernel that the train step puts on a side stream runs beside each kind of aggressor (the
-    LDS-DMA conv kernel, the slab weight-gradient kernel, the plane-resident conv) and must reproduce its quiet result bit
-    for bit."""
+    """Regression for the co-residency wrong-result hazard found on MI355X: while the slab weight-gradient
+    kernel or the LDS-DMA conv kernel runs on another stream and shares a SIMD with it, a wave executing a PACKED fp32 instruction
+    with an op_sel operand swizzle (v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[1,0]: what hipcc's SLP vectoriser makes of scalar fp32
+    arithmetic) gets wrong results in lanes 48..63 -- ~1 % of a sum, every run.  It made the state-MLP gradients of the overlapped
+    train step differ from run to run (round 2) and the SSIM sums come out low (round 3); rounds 2-3 took it for an LDS effect.
+    The library is now built without packed fp32 instructions (tests/test_host_logic.py::test_no_packed_fp32_instructions audits
+    the ISA).  Here every non-MFMA kernel that the train step (or an evaluation) may put on a side stream runs beside each kind of
+    aggressor (the LDS-DMA conv kernel, the slab weight-gradient kernel, the plane-resident conv) and must reproduce its quiet result
+    bit for bit -- all of them, the PSNR / SSIM kernel included."""
     from s2p_amd import ops, metrics
     from s2p_amd.models.networks.layers import ConvLayer
     opt, model, spec, pg, pd, pv = build("bf16", tmp_path)
