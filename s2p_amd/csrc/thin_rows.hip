@@ -272,9 +272,22 @@ __global__ __launch_bounds__(256) void thin_cin_fwd_kernel(const CinArgs a) {
   __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
   const float ns = a.act == S2P_ACT_RELU ? 0.f : (a.act == S2P_ACT_LRELU ? a.slope : 1.f);
   const int HoWo = a.Ho * a.Wo;
-  for (int tile = blockIdx.x * 4 + wave; tile < a.tiles; tile += gridDim.x * 4) {
-    const int m = tile * 32 + nl;
-    const bool mok = m < a.M;
+  // bias of this lane's 32 channels, once per workgroup (it was re-loaded for every tile: 32 dependent global loads in each epilogue)
+  float bb[2][16];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int co = co_base + ct * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+      bb[ct][i] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+    }
+  static_assert(NK <= 8, "all K steps of a tile are loaded as one batch");
+  // every K step's pixel load of a tile is issued as ONE batch, and the batch of the wave's NEXT tile goes out before the current
+  // tile's MFMAs and epilogue (a wave walks ~7 tiles: with the loads issued at the top of each tile the kernel was a chain of
+  // load -> MFMA -> epilogue latencies, 58 us for the 3 -> 1536 conditioning conv against 15 us of HBM time for its output)
+  auto issue_tile = [&](int tile, u32x4 (&bq)[NK], bool& mok, int& m) {
+    m = tile * 32 + nl;
+    mok = m < a.M;
     const int mm = mok ? m : 0;
     const int n = mm / HoWo, rr = mm - n * HoWo, oy = rr / a.Wo, ox = rr - oy * a.Wo;
     unsigned rowoff[KS], coloff[KS];
@@ -291,17 +304,24 @@ __global__ __launch_bounds__(256) void thin_cin_fwd_kernel(const CinArgs a) {
       rowoff[k] = yok ? (unsigned)(((n * a.H + iy) * a.W) * 16) : OOB;
       coloff[k] = xok ? (unsigned)(ix * 16) : OOB;
     }
-    // K steps in chunks of CH: the loads of chunk c+1 are in flight under the MFMAs of chunk c.  (Written out as a
-    // two-buffer pipeline: left to itself hipcc hoists all 2*NK weight fragments into registers and then waits for every
-    // pixel load right where it is issued.)
-    constexpr int CH = NK > 8 ? 5 : NK, NCHUNK = (NK + CH - 1) / CH;
-    auto load_step = [&](int s) -> u32x4 {
+#pragma unroll
+    for (int s = 0; s < NK; ++s) {
       const int t0 = 2 * s, t1 = 2 * s + 1 < T ? 2 * s + 1 : T - 1;           // the odd half of the last step has zero weights
       const unsigned o0 = rowoff[t0 / KS] | coloff[t0 % KS], o1 = rowoff[t1 / KS] | coloff[t1 % KS];
       const unsigned s0 = rowoff[t0 / KS] + coloff[t0 % KS], s1 = rowoff[t1 / KS] + coloff[t1 % KS];
       const unsigned off = h ? ((o1 & OOB) ? OOB : s1) : ((o0 & OOB) ? OOB : s0);
-      return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)off, 0, 0));
-    };
+      bq[s] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)off, 0, 0));
+    }
+  };
+  const int tstride = gridDim.x * 4;
+  int tile = blockIdx.x * 4 + wave;
+  u32x4 cur[NK], nxt[NK];
+  bool mok = false, mok_n = false;
+  int m = 0, m_n = 0;
+  if (tile < a.tiles) issue_tile(tile, cur, mok, m);
+  for (; tile < a.tiles; tile += tstride) {
+    const bool more = tile + tstride < a.tiles;                  // wave-uniform
+    if (more) issue_tile(tile + tstride, nxt, mok_n, m_n);
     const char* wf = smem;
     asm volatile("" : "+v"(wf));                         // opaque per tile: the fragment reads stay in the loop
     f32x16 acc[2];
@@ -309,29 +329,14 @@ __global__ __launch_bounds__(256) void thin_cin_fwd_kernel(const CinArgs a) {
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[ct][e] = 0.f;
-    u32x4 bq[2][CH];
 #pragma unroll
-    for (int i = 0; i < CH; ++i) bq[0][i] = load_step(i);
+    for (int s = 0; s < NK; ++s) {
+      const bf16x8 bf = __builtin_bit_cast(bf16x8, cur[s]);
 #pragma unroll
-    for (int c = 0; c < NCHUNK; ++c) {
-      if (c + 1 < NCHUNK) {
-#pragma unroll
-        for (int i = 0; i < CH; ++i)
-          if ((c + 1) * CH + i < NK) bq[(c + 1) & 1][i] = load_step((c + 1) * CH + i);
+      for (int ct = 0; ct < 2; ++ct) {
+        const bf16x8 af = *(const bf16x8*)(wf + ((size_t)(ct * NK + s) * 64 + lane) * 16);
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[ct], 0, 0, 0);
       }
-#pragma unroll
-      for (int i = 0; i < CH; ++i) {
-        const int s = c * CH + i;
-        if (s < NK) {
-          const bf16x8 bf = __builtin_bit_cast(bf16x8, bq[c & 1][i]);
-#pragma unroll
-          for (int ct = 0; ct < 2; ++ct) {
-            const bf16x8 af = *(const bf16x8*)(wf + ((size_t)(ct * NK + s) * 64 + lane) * 16);
-            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[ct], 0, 0, 0);
-          }
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
     }
     // bias + activation, pack to bf16: pk[ct][q] = channels co_base + 32 ct + 8 q + 4 h + (0..3) of this lane's pixel
     u32x2 pk[2][4];
@@ -342,8 +347,7 @@ __global__ __launch_bounds__(256) void thin_cin_fwd_kernel(const CinArgs a) {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int co = co_base + ct * 32 + 8 * q + 4 * h + e;
-          float t = acc[ct][4 * q + e] + ((a.bias && co < a.Cout) ? a.bias[co] : 0.f);
+          float t = acc[ct][4 * q + e] + bb[ct][4 * q + e];
           v[e] = t > 0.f ? t : t * ns;
         }
         const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
@@ -363,6 +367,10 @@ __global__ __launch_bounds__(256) void thin_cin_fwd_kernel(const CinArgs a) {
         const int co0 = co_base + ct * 32 + 8 * (2 * h + k);
         if (mok && co0 < a.Cout) *(u32x4*)(yp + co0) = out;
       }
+    // the prefetched batch becomes the current one
+#pragma unroll
+    for (int s = 0; s < NK; ++s) cur[s] = nxt[s];
+    mok = mok_n; m = m_n;
   }
 }
 
