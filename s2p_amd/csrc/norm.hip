@@ -119,43 +119,7 @@ __global__ __launch_bounds__(256) void in_reduce_kernel(const NormArgs a) {
     }
   }
   if (cok) {
-    int p = p_begin + pr;
-    // The big planes (84x84 / 42x42 encoder, decoder and VGG-sized maps) walk ~14 pixels per thread: with one 16-byte load in flight
-    // per thread the pass is latency-bound (2.5 TB/s).  Batches of four pixels keep four (forward) / eight (backward) loads in flight.
-    if constexpr (MODE == 0) {
-      for (; p + 3 * PR < p_end; p += 4 * PR) {
-        Chunk<T> xq[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) xq[u].raw = *(const u32x4*)(xb + (size_t)(p + u * PR) * a.x_pitch);
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int e = 0; e < CE; ++e) { float v = xq[u].get(e) - mean[e]; q[0][e] += v; q[1][e] = __builtin_fmaf(v, v, q[1][e]); }
-      }
-    } else {
-      if (!a.gb) {
-        const T* dab = (const T*)a.da + (size_t)n * a.HW * a.da_pitch + c0;
-        for (; p + 3 * PR < p_end; p += 4 * PR) {
-          Chunk<T> xq[4], dq[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            xq[u].raw = *(const u32x4*)(xb + (size_t)(p + u * PR) * a.x_pitch);
-            dq[u].raw = *(const u32x4*)(dab + (size_t)(p + u * PR) * a.da_pitch);
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int e = 0; e < CE; ++e) {
-              float xh;
-              float yv = mat_value(xq[u].get(e), mean[e], rstd[e], gs[e], bs[e], xh);
-              float dy = dq[u].get(e) * (yv > 0.f ? 1.f : gneg);
-              float dxh = dy * gs[e];
-              q[0][e] += dxh; q[1][e] += dxh * xh; q[2][e] += dy * xh; q[3][e] += dy;
-            }
-        }
-      }
-    }
-    for (; p < p_end; p += PR) {
+    for (int p = p_begin + pr; p < p_end; p += PR) {
       Chunk<T> xv; xv.raw = *(const u32x4*)(xb + (size_t)p * a.x_pitch);
       if constexpr (MODE == 0) {
 #pragma unroll
@@ -269,35 +233,7 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const NormArgs a) {
   const T* dab = MODE == 1 ? (const T*)a.da + img * a.da_pitch + c0 : nullptr;
   T* yb = (T*)a.y + img * a.y_pitch + c0;
   T* dgb = (MODE == 1 && a.dgb) ? (T*)a.dgb + img * a.dgb_pitch + c0 : nullptr;
-  int p = p_begin + pr;
-  if (!gbb && !act_generic && !dgb) {
-    // plain InstanceNorm (+ relu / lrelu) on a big plane: four pixels per batch, every load of the batch in flight before the first use
-    // (one load in flight per thread left the pass latency-bound: in_reduce_kernel)
-    for (; p + 3 * PR < p_end; p += 4 * PR) {
-      Chunk<T> xq[4], dq[4], oq[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        xq[u].raw = *(const u32x4*)(xb + (size_t)(p + u * PR) * a.x_pitch);
-        if (MODE == 1) dq[u].raw = *(const u32x4*)(dab + (size_t)(p + u * PR) * a.da_pitch);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-#pragma unroll
-        for (int e = 0; e < CE; ++e) {
-          float xh;
-          float yv = mat_value(xq[u].get(e), mean[e], rstd[e], gs[e], bs[e], xh);
-          if (MODE == 0) oq[u].set(e, yv > 0.f ? yv : yv * ns);
-          else {
-            float dy = dq[u].get(e) * (yv > 0.f ? 1.f : ns);
-            float dxh = dy * gs[e];
-            oq[u].set(e, rstd[e] * (dxh - s1[e] - xh * s2[e]));
-          }
-        }
-        *(u32x4*)(yb + (size_t)(p + u * PR) * a.y_pitch) = oq[u].raw;
-      }
-    }
-  }
-  for (; p < p_end; p += PR) {
+  for (int p = p_begin + pr; p < p_end; p += PR) {
     Chunk<T> xv; xv.raw = *(const u32x4*)(xb + (size_t)p * a.x_pitch);
     Chunk<T> gv, bv, dv;
     if (gbb) { gv.raw = *(const u32x4*)(gbb + (size_t)p * a.gb_pitch); bv.raw = *(const u32x4*)(gbb + (size_t)p * a.gb_pitch + a.C); }
