@@ -1293,9 +1293,9 @@ static int launch_fast(GatherArgs& a, int groups, hipStream_t st) {
       }
     }
   }
-  // other small planes -- the PatchGAN 4x4 layers and their stride-1 dgrads: the generalised plane-resident kernel (conv_planeg.hip),
-  // with the InstanceNorm that follows (forward) / precedes (backward) the conv in its epilogue
-  if (!no_plane && !S2P_DIAG_SWITCH(0) && !no_dma && groups == 1 && a.nphase == 0 && a.T != 9 && a.ostride == 1 && a.oy0 == 0 && a.ox0 == 0 && a.Qh == a.Ho &&
+  // other small planes -- the PatchGAN 4x4 layers and their stride-1 dgrads (with the InstanceNorm that follows (forward) / precedes
+  // (backward) the conv in the epilogue), VGG conv4_x on 10x10 maps: the generalised plane-resident kernel (conv_planeg.hip)
+  if (!no_plane && !S2P_DIAG_SWITCH(0) && !(a.T == 9 && S2P_DIAG_SWITCH(2)) && !no_dma && groups == 1 && a.nphase == 0 && a.ostride == 1 && a.oy0 == 0 && a.ox0 == 0 && a.Qh == a.Ho &&
       a.Qw == a.Wo && a.M % (a.Qh * a.Qw) == 0 && !a.reflect) {
     PlaneGProblem pr{a.M / (a.Qh * a.Qw), a.Hi, a.Wi, a.Ho, a.Wo, a.Cin, a.Cout, a.Cst, a.x_pitch, a.y_pitch, a.istride, a.T, a.tap};
     PlaneGArgs p{};

@@ -550,8 +550,9 @@ __global__ __launch_bounds__(512) void conv_planeg_kernel(const PlaneGArgs a) {
 namespace {
 struct PgShape { int TY, TX, PB, NPB, S2D; };
 // instantiated shapes: 4x4 stride 1 on planes up to 64 / 192 produced pixels (the 256 -> 512 layers of both scales and their dgrads);
-// 4x4 stride 2 pad 2 in the parity form (2x2 raster taps) on the same tile sizes (128 -> 256 of both scales, 64 -> 128 of the coarser)
-const PgShape PG_SHAPES[] = {{4, 4, 1, 128, 0}, {4, 4, 3, 256, 0}, {2, 2, 1, 128, 1}, {2, 2, 3, 256, 1}};
+// 4x4 stride 2 pad 2 in the parity form (2x2 raster taps) on the same tile sizes (128 -> 256 of both scales, 64 -> 128 of the coarser);
+// 3x3 stride 1 on planes of 65..128 produced pixels (VGG conv4_x on 10x10 maps and their dgrads: too small for conv_plane.hip's tile)
+const PgShape PG_SHAPES[] = {{4, 4, 1, 128, 0}, {4, 4, 3, 256, 0}, {2, 2, 1, 128, 1}, {2, 2, 3, 256, 1}, {3, 3, 2, 256, 0}};
 }  // namespace
 
 static bool pg_pick_shape(PlaneGArgs& a, int TY, int TX, int s2d) {
@@ -616,7 +617,7 @@ bool s2p_conv_planeg_setup(const PlaneGProblem& p, PlaneGArgs& a) {
 
 template <int TY, int TX, int PB, int NPB, bool S2D>
 static void pg_launch_shape(const PlaneGArgs& a, dim3 grid, hipStream_t st) {
-  constexpr int RING = 8;
+  constexpr int RING = (2 * TY * TX) % 8 == 0 ? 8 : 6;          // divides the K steps of an iteration
   if (a.y2 && a.xn) hipLaunchKernelGGL((conv_planeg_kernel<TY, TX, PB, NPB, RING, 2, S2D, false>), grid, dim3(512), 0, st, a);
   else if (a.y2) hipLaunchKernelGGL((conv_planeg_kernel<TY, TX, PB, NPB, RING, 1, S2D, false>), grid, dim3(512), 0, st, a);
   else hipLaunchKernelGGL((conv_planeg_kernel<TY, TX, PB, NPB, RING, 0, S2D, false>), grid, dim3(512), 0, st, a);
@@ -630,6 +631,7 @@ int s2p_conv_planeg_launch(PlaneGArgs& a, int groups, hipStream_t st) {
   else if (a.shape == 1) pg_launch_shape<4, 4, 3, 256, false>(a, grid, st);
   else if (a.shape == 2) pg_launch_shape<2, 2, 1, 128, true>(a, grid, st);
   else if (a.shape == 3) pg_launch_shape<2, 2, 3, 256, true>(a, grid, st);
+  else if (a.shape == 4) pg_launch_shape<3, 3, 2, 256, false>(a, grid, st);
   else S2P_FAIL(-1, "conv_planeg: no kernel instantiated for this shape (s2p_conv_planeg_setup decides)");
   S2P_CHECK_LAUNCH("conv_planeg_kernel");
   return 0;

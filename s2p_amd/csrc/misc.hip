@@ -879,7 +879,8 @@ extern "C" __attribute__((visibility("default"))) int s2p_diag_vgpr_canary(int b
   return 0;
 }
 
-// run-time A/B switches (diagnostics build only): 0 = no generalised plane kernel (conv_planeg.hip)
+// run-time A/B switches (diagnostics build only): 0 = no generalised plane kernel (conv_planeg.hip), 1 = the tiled 7x7 thin weight
+// gradient instead of the row-streaming one, 2 = no generalised plane kernel for 3x3 convs (VGG conv4_x)
 int s2p_diag_switch[16] = {0};
 extern "C" __attribute__((visibility("default"))) int s2p_diag_set(int key, int value) {
   if (key < 0 || key >= 16) return -1;

@@ -468,9 +468,10 @@ def test_conv_wgrad_batched_slab(hip_device, case):
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
 
 
-@pytest.mark.parametrize("case", [(256, 512, 4, 2, 7, 7, 8), (256, 256, 4, 2, 12, 12, 6), (512, 128, 2, 1, 9, 8, 5)])
+@pytest.mark.parametrize("case", [(512, 512, 3, 1, 5, 5, 8), (256, 256, 3, 1, 4, 6, 6), (512, 128, 2, 1, 9, 8, 5)])
 def test_conv_small_map_splitk(hip_device, case):
-    """Small maps with a long K (the PatchGAN 256->512 4x4 layers): the launch cannot fill the chip, so K is split over
+    """Small maps with a long K that the plane-resident kernels do not take (VGG conv5_1 on 5x5 maps; since round 4 the PatchGAN
+    256->512 4x4 layers run on csrc/conv_planeg.hip): the launch cannot fill the chip, so K is split over
     blockIdx.z and a second kernel applies bias / activation / epilogue to the fixed-order sum
     (s2p_conv2d_{fwd,dgrad}_ws).  Checks the plain, residual-add and producer-activation-gradient epilogues against float64, that the
     split path is the one taken, and bitwise reproducibility."""
@@ -875,6 +876,29 @@ def test_conv_planeg_4x4_stride1(hip_device, shape):
         d_mid = ops.conv_dgrad(geom, dyd, wb, tuple(xd.shape), cin, aux=tapd if with_tap else None, epi=EPI_ADD if with_tap else EPI_STORE)
         dx2 = ops.in_bwd(d_mid, xnd, cin, st_n, act=ACT_LRELU, slope=0.2)
         assert rel_err(dxn.float().cpu(), dx2.float().cpu().double()) < 1e-2
+
+
+@pytest.mark.parametrize("shape", [(8, 512, 512, 10, 10), (3, 256, 512, 10, 10), (5, 64, 128, 9, 11), (64, 512, 512, 10, 10)])
+def test_conv_planeg_3x3_small_planes(hip_device, shape):
+    """3x3 stride-1 pad-1 convs on planes of 65..128 pixels (VGG conv4_x at 10x10; 9x11 ragged) on the generalised plane-resident
+    kernel (csrc/conv_planeg.hip): forward with bias + ReLU, and the dgrad with the fused producer-activation gradient and a second
+    incoming gradient (the VGG taps), against float64."""
+    dev = hip_device
+    dtype = torch.bfloat16
+    N, cin, cout, H, W = shape
+    pick = list(range(N)) if N <= 8 else [0, 21, 42, 63]
+    g = torch.Generator().manual_seed(31)
+    r = lambda *sh: torch.randn(*sh, generator=g).bfloat16().float()      # noqa: E731
+    x, w, b = r(N, cin, H, W), r(cout, cin, 3, 3) / math.sqrt(cin * 9), torch.randn(cout, generator=g)
+    geom = ops.ConvGeom(cin, cout, 3, 1, 1)
+    xd, wf, wb = nhwc(x, cin, dtype, dev), pack_fwd(w, cin, dtype, dev), pack_bwd(w, cin, cout, dtype, dev)
+    y = ops.conv_fwd(geom, xd, wf, b.to(dev), cin, act=ACT_RELU)
+    assert rel_err(nchw(y, cout)[pick], F.relu(F.conv2d(x[pick].double(), w.double(), b.double(), padding=1))) < TOL[dtype]
+    a, dy, d2 = F.relu(x), r(N, cout, H, W), r(N, cin, H, W)
+    dx = ops.conv_dgrad(geom, nhwc(dy, cout, dtype, dev), wb, tuple(xd.shape), cin, aux=nhwc(a, cin, dtype, dev), epi=EPI_MUL_ACTGRAD,
+                        aux_act=ACT_RELU, aux2=nhwc(d2, cin, dtype, dev))
+    ref = (F.conv_transpose2d(dy[pick].double(), w.double(), padding=1) + d2[pick].double()) * (a[pick] > 0).double()
+    assert rel_err(nchw(dx, cin)[pick], ref) < TOL[dtype]
 
 
 @pytest.mark.parametrize("shape", [
