@@ -189,7 +189,7 @@ def count_flips(masks, trace64):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("precision,tol,gtol,max_flips", [("fp32", 1e-5, 1e-5, 24), ("bf16", 3e-2, 0.10, 30000)])   # measured: fp32 grads 3.4e-6; bf16 grads 5.0e-2, 15 228 flips
+@pytest.mark.parametrize("precision,tol,gtol,max_flips", [("fp32", 1e-5, 1e-5, 24), ("bf16", 2.3e-2, 0.08, 23000)])   # bf16 bounds = 1.5 x measured (round 4): forward 1.50e-2, grads 5.12e-2, 15 271 flips; fp32 grads 3.4e-6
 def test_generator_forward_backward(hip_device, tmp_path, precision, tol, gtol, max_flips):
     opt, model, spec, pg, pd, pv = build(precision, tmp_path)
     prev, state, real = make_inputs(2, 84, 84, 17)
@@ -306,7 +306,7 @@ def test_full_batch_forward_bf16(hip_device, tmp_path):
         y_ref = O.generator_forward(pg64, prev[pick].double(), state[pick].double(), spec)
         e = rel_l2(y.detach().cpu()[pick], y_ref)
         print("bs-64 bf16 generator forward vs float64 on samples %s: rel-L2 %.2e" % (pick, e))
-        assert e < 3e-2
+        assert e < 2.3e-2                                   # 1.5 x measured (1.52e-2)
         C = model.netG.c_mid
         w64 = O.state_mapping(pg64, state[pick].double(), spec)
         blocks = c["blocks"]
@@ -322,7 +322,7 @@ def test_full_batch_forward_bf16(hip_device, tmp_path):
             print("MAT-ResBlk %d (isolated, bs 64 bf16 vs float64): %s" % (b, {k: "%.1e" % v for k, v in errs.items()}))
             for k, v in errs.items():
                 worst[k] = max(worst.get(k, 0.0), v)
-                assert v < 2e-2, (b, k, v)
+                assert v < 6.5e-3, (b, k, v)               # 1.5 x measured (nA 2.4e-3, c0 3.4e-3, nB 4.1e-3, out 3.9e-3)
         assert min(worst.values()) > 1e-4          # bf16 rounding is visible: the comparison saw real data
         x = torch.cat([prev, real], 1)
         feats = model.netD(x.cuda())
@@ -332,7 +332,7 @@ def test_full_batch_forward_bf16(hip_device, tmp_path):
                 assert f.shape[0] == N and f.shape[1:] == r_.shape[1:]
                 e = rel_l2(f.cpu()[pick], r_)
                 print("D scale %d feature %d (bs 64 bf16 vs float64): rel-L2 %.2e" % (k, j, e))
-                assert e < 3e-2, (k, j, e)
+                assert e < 1.2e-2, (k, j, e)                # 1.5 x measured (8.0e-3 at the deepest feature)
 
 
 @pytest.mark.parametrize("N,S", [(1, 100), (3, 44)])
@@ -357,7 +357,7 @@ def test_edge_shapes_generator_and_discriminator_features(hip_device, tmp_path, 
             assert rel_l2(f.cpu(), r_) < 1e-5
 
 
-@pytest.mark.parametrize("precision,ltol,gtol,dgtol,env", [("fp32", 1e-4, 1e-5, 1e-5, "cheetah"), ("bf16", 5e-3, 0.10, 2.2e-2, "cheetah"),
+@pytest.mark.parametrize("precision,ltol,gtol,dgtol,env", [("fp32", 1e-4, 1e-5, 1e-5, "cheetah"), ("bf16", 5e-3, 0.08, 1.6e-2, "cheetah"),
                                                            ("fp32", 1e-4, 1e-5, 1e-5, "walker")])   # measured: fp32 4.1e-6 / 3.4e-6, bf16 5.3e-2 / 1.07e-2
 def test_train_step_losses_and_grads(hip_device, tmp_path, precision, ltol, gtol, dgtol, env):
     """One G step and one D step (hinge GAN + feature matching + VGG + L1): every loss value and every parameter gradient
@@ -665,7 +665,7 @@ def test_full_size_shard_additivity_bf16(hip_device, tmp_path):
         print(f"shard additivity {name}: {err:.3e}")
         # bf16 operands; the IN split geometry depends on the batch, so a LeakyReLU input may round to the other side of 0
         # and flip a 4x4 footprint of the D gradient (measured: G 1e-2, D 4e-2)
-        assert err < (2.5e-2 if name == "G" else 8e-2), (name, err)          # measured 1.2e-2 (G), 4.0e-2 (D): twice that
+        assert err < (1.8e-2 if name == "G" else 6e-2), (name, err)          # 1.5 x measured: 1.2e-2 (G), 3.2e-2 .. 4.0e-2 (D, branch flips: varies with the build)
 
 
 def test_walker_trainer_step_full_batch_bf16(hip_device, tmp_path):
