@@ -29,7 +29,7 @@ extern "C" {
 /* the library is built with -fvisibility=hidden: only the entry points declared here are exported */
 #pragma GCC visibility push(default)
 
-#define S2P_VERSION 115
+#define S2P_VERSION 116
 
 enum { S2P_F32 = 0, S2P_BF16 = 1 };
 enum { S2P_ACT_NONE = 0, S2P_ACT_RELU = 1, S2P_ACT_LRELU = 2, S2P_ACT_TANH = 3, S2P_ACT_SWISH = 4 };
@@ -57,6 +57,9 @@ typedef struct {
                            (whole tensors `stride` elements apart), e.g. the 12 gamma|beta
                            planes of the generator, one 1-KB-row tensor per norm            */
   int32_t x_gstride, y_gstride;
+  int32_t cin_real;     /* un-padded input channels (0: unknown = Cin).  Lets the thin-input kernels skip zero
+                           padding channels: a 7x7 conv with <= 4 real input channels (the generator's stem)
+                           contracts 4 channels per tap instead of 8                                        */
 } s2p_conv_desc;
 
 int s2p_version(void);

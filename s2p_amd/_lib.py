@@ -22,7 +22,7 @@ c_int, c_float, c_void_p, c_int64 = ctypes.c_int, ctypes.c_float, ctypes.c_void_
 class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "dtype", "N", "H", "W", "Cin", "x_pitch", "Ho", "Wo", "Cout", "y_pitch",
-        "KH", "KW", "stride", "pad", "transposed", "reflect", "groups", "x_gstride", "y_gstride")]
+        "KH", "KW", "stride", "pad", "transposed", "reflect", "groups", "x_gstride", "y_gstride", "cin_real")]
 
 
 class L1Job(ctypes.Structure):
@@ -137,7 +137,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the export is missing
             fn.argtypes = args
             fn.restype = _RESTYPE.get(name, c_int)
-        if L.s2p_version() < 115:
+        if L.s2p_version() < 116:
             raise RuntimeError("libs2p_hip.so is older than this package")
         _lib = L
     return _lib

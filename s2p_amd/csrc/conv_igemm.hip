@@ -1541,6 +1541,10 @@ static int conv_fwd_impl(const s2p_conv_desc* d, const void* x, const void* w_fw
   hipStream_t st = (hipStream_t)stream;
   int ce = d->dtype == S2P_F32 ? 4 : 8;
   if (epi == S2P_EPI_STORE && s2p_thin_applicable(d)) return sc.plan ? 0 : s2p_thin_fwd(d, x, w_fwd, bias, y, act, slope, st);
+  if (!S2P_DIAG_SWITCH(3) && s2p_thin4_fwd_applicable(d, act, epi)) {      // 7x7, <= 4 real input channels (the generator's stem)
+    if (sc.plan) { const size_t need = s2p_thin4_fwd_ws_bytes(d); if (need > *sc.plan) *sc.plan = need; return 0; }
+    if (sc.ws && sc.bytes >= s2p_thin4_fwd_ws_bytes(d)) return s2p_thin4_fwd(d, x, w_fwd, bias, y, act, slope, sc.ws, sc.bytes, st);
+  }
   static const int no_cin = s2p_env_set("S2P_NO_THIN_CIN");          // A/B switch (diagnostics build only)
   if (!no_cin && s2p_thin_cin_fwd_applicable(d, act, epi)) return sc.plan ? 0 : s2p_thin_cin_fwd(d, x, w_fwd, bias, y, act, slope, st);
   Geo G{d->N, d->H, d->W, d->Cin, d->x_pitch, d->x_gstride, d->Ho, d->Wo, d->Cout,
@@ -1601,6 +1605,10 @@ static int conv_dgrad_impl(const s2p_conv_desc* d, const void* dy, const void* w
   int ce = d->dtype == S2P_F32 ? 4 : 8;
   int cout_pad = (d->Cout + ce - 1) / ce * ce;       // channels of dy actually gathered
   if (cout_pad > d->y_pitch) S2P_FAIL(-1, "s2p_conv2d_dgrad: dy pitch %d < padded Cout %d", d->y_pitch, cout_pad);
+  if (!S2P_DIAG_SWITCH(3) && epi == S2P_EPI_STORE && s2p_thin4_dgrad_applicable(d, cout_pad)) {      // 7x7, <= 4 output channels (the generator's output conv)
+    if (sc.plan) { const size_t need = s2p_thin4_dgrad_ws_bytes(d); if (need > *sc.plan) *sc.plan = need; return 0; }
+    if (sc.ws && sc.bytes >= s2p_thin4_dgrad_ws_bytes(d)) return s2p_thin4_dgrad(d, dy, w_bwd, dx, cout_pad, sc.ws, sc.bytes, st);
+  }
   // thin input (<= 8 channels), stride 1: the adjoint is a thin-Cout conv over dy (row-streaming kernel, thin_rows.hip)
   if (epi == S2P_EPI_STORE && s2p_thin_rows_dgrad_applicable(d, cout_pad))
     return sc.plan ? 0 : s2p_thin_rows_dgrad(d, dy, w_bwd, dx, cout_pad, st);

@@ -156,6 +156,14 @@ int s2p_thin_rows_dgrad(const s2p_conv_desc* d, const void* dy, const void* w_bw
 bool s2p_thin_cin_fwd_applicable(const s2p_conv_desc* d, int act, int epi);
 int s2p_thin_cin_fwd(const s2p_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int act, float slope,
                      hipStream_t st);
+// 7x7 convs with <= 4 real channels on the thin side, 4-channel-pitch padded copy + 14-step MFMA kernel (thin_rows.hip)
+bool s2p_thin4_fwd_applicable(const s2p_conv_desc* d, int act, int epi);
+size_t s2p_thin4_fwd_ws_bytes(const s2p_conv_desc* d);
+int s2p_thin4_fwd(const s2p_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int act, float slope, void* ws,
+                  size_t ws_bytes, hipStream_t st);
+bool s2p_thin4_dgrad_applicable(const s2p_conv_desc* d, int cout_pad);
+size_t s2p_thin4_dgrad_ws_bytes(const s2p_conv_desc* d);
+int s2p_thin4_dgrad(const s2p_conv_desc* d, const void* dy, const void* w_bwd, void* dx, int cout_pad, void* ws, size_t ws_bytes, hipStream_t st);
 // PatchGAN logit heads, Cout = 1 (wgrad_head.hip)
 bool s2p_head_wgrad_supported(const s2p_conv_desc* d, int cin_real, int cout_real);
 size_t s2p_head_wgrad_workspace(const s2p_conv_desc* d);

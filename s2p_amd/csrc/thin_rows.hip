@@ -404,3 +404,207 @@ int s2p_thin_cin_fwd(const s2p_conv_desc* d, const void* x, const void* w, const
   S2P_CHECK_LAUNCH("thin_cin_fwd_kernel");
   return 0;
 }
+
+
+// ================================================================================================================
+// 7x7 stride-1 convolutions with at most FOUR real input channels (the generator's stem 3 -> 64, and -- over dY with flipped taps --
+// the dgrad of its 64 -> 3 output conv), forward, bf16 (round 4).  The implicit-GEMM kernels contract 8 channels per tap (the 16-byte
+// chunk of a thin tensor: 5 of them zero): 13 MFMA k-steps per tile, 62 us for the stem against 10 us of HBM time for its output.
+// Here the input is first copied into a PRE-PADDED tensor with a 4-channel pitch ([N][Ho + 6][Wo + 8][4], 8 bytes per pixel;
+// reflect or zero padding is resolved by that copy: 4 MB), in which the four taps kx .. kx + 3 of a pixel row are 32 CONTIGUOUS
+// bytes: one v_mfma_f32_32x32x16_bf16 step contracts four taps (the lane halves take two each, 16 bytes at an 8-byte-aligned
+// address straight from global memory), a tap row is two steps (kx = 7 has zero weights), the conv 14 steps of half the
+// K -- and no border logic in the kernel.  Otherwise the kernel is thin_cin_fwd_kernel: weights in LDS in fragment order, a wave
+// owns 32 consecutive output pixels x 64 channels, the lane halves swap 8-byte pieces so that every store is a full chunk.
+struct Thin4Args {
+  const __bf16* xp; const __bf16* w; const float* bias; __bf16* y;
+  int N, Ho, Wo, Hp, Wp, Cout, y_pitch, act, w_row, w_tap, flip;      // w[(co * w_row + tap * w_tap + ch)]: forward [Cout][49][8], dgrad use [Cin][49][cout_pad]
+  float slope;
+  int M, tiles, xp_bytes;
+};
+struct Pad4Args { const __bf16* x; __bf16* xp; int N, H, W, x_pitch, Hp, Wp, pad, reflect; };
+
+// xp[n][yp][xq][0..3] = x[n][yp - pad][xq - pad][0..3] (reflected or zero outside; columns >= W + 2 pad are zero)
+__global__ __launch_bounds__(256) void pad4_kernel(const Pad4Args a) {
+  const long long total = (long long)a.N * a.Hp * a.Wp;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int xq = (int)(i % a.Wp);
+    const long long r = i / a.Wp;
+    const int yp = (int)(r % a.Hp), n = (int)(r / a.Hp);
+    int iy = yp - a.pad, ix = xq - a.pad;
+    bool ok = xq < a.W + 2 * a.pad;
+    if (a.reflect) {
+      iy = iy < 0 ? -iy : (iy >= a.H ? 2 * a.H - 2 - iy : iy);
+      ix = ix < 0 ? -ix : (ix >= a.W ? 2 * a.W - 2 - ix : ix);
+      ok = ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    } else {
+      ok = ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    }
+    u32x2 v = {0u, 0u};
+    if (ok) v = *(const u32x2*)(a.x + (((size_t)n * a.H + iy) * a.W + ix) * a.x_pitch);
+    *(u32x2*)(a.xp + (size_t)i * 4) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void thin4_fwd_kernel(const Thin4Args a) {
+  constexpr int NK = 14;                                              // K steps: (ky, half row): taps kx = 4 j .. 4 j + 3
+  __shared__ __attribute__((aligned(16))) char smem[2 * NK * 1024];   // [2 co tiles][NK] fragments of 64 lanes x 16 B
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int co_base = blockIdx.y * 64;
+  // weights -> fragment order: A[m = co][k = 8 hh + e] of step (ky, j): tap kx = 4 j + 2 hh + (e >> 2), channel e & 3
+  for (int f = tid; f < 2 * NK * 64; f += 256) {
+    const int ln = f & 63, s = (f >> 6) % NK, ct = f / (64 * NK);
+    const int co = co_base + ct * 32 + (ln & 31), hh = ln >> 5, ky = s >> 1, j = s & 1;
+    unsigned short e8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int kx = 4 * j + 2 * hh + (e >> 2), ch = e & 3;
+      unsigned short v = 0;
+      if (co < a.Cout && kx < 7) {
+        const int t = ky * 7 + kx, tap = a.flip ? 48 - t : t;
+        v = *(const unsigned short*)(a.w + (size_t)co * a.w_row + (size_t)tap * a.w_tap + ch);
+      }
+      e8[e] = v;
+    }
+    u32x4 o = {(unsigned)e8[0] | ((unsigned)e8[1] << 16), (unsigned)e8[2] | ((unsigned)e8[3] << 16),
+               (unsigned)e8[4] | ((unsigned)e8[5] << 16), (unsigned)e8[6] | ((unsigned)e8[7] << 16)};
+    *(u32x4*)(smem + (size_t)f * 16) = o;
+  }
+  __syncthreads();
+  const int nl = lane & 31, h = lane >> 5;
+  __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.xp, 0, a.xp_bytes, 0x00020000);
+  const float ns = a.act == S2P_ACT_RELU ? 0.f : (a.act == S2P_ACT_LRELU ? a.slope : 1.f);
+  const bool tanh_act = a.act == S2P_ACT_TANH;
+  const int HoWo = a.Ho * a.Wo;
+  float bb[2][16];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int co = co_base + ct * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+      bb[ct][i] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+    }
+  for (int tile = blockIdx.x * 4 + wave; tile < a.tiles; tile += gridDim.x * 4) {
+    const int m = tile * 32 + nl;
+    const bool mok = m < a.M;
+    const int mm = mok ? m : 0;
+    const int n = mm / HoWo, rr = mm - n * HoWo, oy = rr / a.Wo, ox = rr - oy * a.Wo;
+    // byte offset of (row oy + ky, column ox + 2 h): + ky * Wp * 8, + j * 32
+    const unsigned base = (unsigned)((((size_t)n * a.Hp + oy) * a.Wp + ox + 2 * h) * 8);
+    u32x4 bq[NK];
+#pragma unroll
+    for (int s = 0; s < NK; ++s)
+      bq[s] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(base + (unsigned)((s >> 1) * a.Wp * 8 + (s & 1) * 32)), 0, 0));
+    const char* wf = smem;
+    asm volatile("" : "+v"(wf));                         // opaque per tile: the fragment reads stay in the loop
+    f32x16 acc[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[ct][e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NK; ++s) {
+      const bf16x8 bf = __builtin_bit_cast(bf16x8, bq[s]);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const bf16x8 af = *(const bf16x8*)(wf + ((size_t)(ct * NK + s) * 64 + lane) * 16);
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[ct], 0, 0, 0);
+      }
+    }
+    // bias + activation, pack to bf16: pk[ct][q] = channels co_base + 32 ct + 8 q + 4 h + (0..3) of this lane's pixel
+    u32x2 pk[2][4];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = acc[ct][4 * q + e] + bb[ct][4 * q + e];
+          v[e] = tanh_act ? tanhf(t) : (t > 0.f ? t : t * ns);
+        }
+        const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        pk[ct][q] = __builtin_bit_cast(u32x2, o);
+      }
+    // half 0 stores the chunks q = 0, 1 (it needs the partner's 8 bytes of those), half 1 the chunks q = 2, 3
+    __bf16* yp = a.y + (size_t)m * a.y_pitch;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const u32x2 give = h ? pk[ct][k] : pk[ct][2 + k];
+        u32x2 got;
+        got[0] = (unsigned)__shfl_xor((int)give[0], 32, 64); got[1] = (unsigned)__shfl_xor((int)give[1], 32, 64);
+        const u32x2 own = h ? pk[ct][2 + k] : pk[ct][k];
+        const u32x4 out = h ? (u32x4){got[0], got[1], own[0], own[1]} : (u32x4){own[0], own[1], got[0], got[1]};
+        const int co0 = co_base + ct * 32 + 8 * (2 * h + k);
+        if (mok && co0 < a.Cout) *(u32x4*)(yp + co0) = out;
+      }
+  }
+}
+
+// forward use: 7x7 stride 1 pad 3 (reflect or zero), <= 4 real input channels in an 8-pitch tensor, Cout a multiple of 8
+bool s2p_thin4_fwd_applicable(const s2p_conv_desc* d, int act, int epi) {
+  if (!(d->dtype == S2P_BF16 && d->groups == 1 && !d->transposed && d->Cin == 8 && d->x_pitch == 8 && d->KH == 7 && d->KW == 7 &&
+        d->stride == 1 && d->pad == 3 && d->cin_real >= 1 && d->cin_real <= 4))
+    return false;
+  if (epi != S2P_EPI_STORE || act == S2P_ACT_SWISH) return false;
+  if (d->Cout % 8 || d->Cout < 32 || d->y_pitch % 8 || d->Ho != d->H || d->Wo != d->W) return false;
+  if (d->reflect && (d->H < 4 || d->W < 4)) return false;
+  return (long long)d->N * (d->H + 6) * (d->W + 8) * 8 < (1ll << 31) && (long long)d->N * d->H * d->W < (1ll << 31) - 64;
+}
+size_t s2p_thin4_fwd_ws_bytes(const s2p_conv_desc* d) { return (size_t)d->N * (d->H + 6) * (d->W + 8) * 8; }
+
+static int thin4_launch(Thin4Args& a, const Pad4Args& p, hipStream_t st) {
+  const long long total = (long long)p.N * p.Hp * p.Wp;
+  int pb = (int)((total + 255) / 256); if (pb > 4096) pb = 4096;
+  hipLaunchKernelGGL(pad4_kernel, dim3(pb), dim3(256), 0, st, p);
+  S2P_CHECK_LAUNCH("pad4_kernel");
+  a.M = a.N * a.Ho * a.Wo; a.tiles = cdiv(a.M, 32);
+  a.xp_bytes = (int)(total * 8);
+  const int ncb = cdiv(a.Cout, 64);
+  int gx = cdiv(a.tiles, 4);
+  const int cap = 1024 / ncb > 32 ? 1024 / ncb : 32;
+  if (gx > cap) gx = cap;
+  hipLaunchKernelGGL(thin4_fwd_kernel, dim3(gx, ncb), dim3(256), 0, st, a);
+  S2P_CHECK_LAUNCH("thin4_fwd_kernel");
+  return 0;
+}
+
+int s2p_thin4_fwd(const s2p_conv_desc* d, const void* x, const void* w, const float* bias, void* y, int act, float slope, void* ws,
+                  size_t ws_bytes, hipStream_t st) {
+  if (!ws || ws_bytes < s2p_thin4_fwd_ws_bytes(d)) S2P_FAIL(-1, "s2p_conv2d_fwd: this 7x7 thin-input conv needs %zu bytes of workspace (s2p_conv2d_fwd_workspace)", s2p_thin4_fwd_ws_bytes(d));
+  Pad4Args p{(const __bf16*)x, (__bf16*)ws, d->N, d->H, d->W, d->x_pitch, d->H + 6, d->W + 8, 3, d->reflect};
+  Thin4Args a{};
+  a.xp = (const __bf16*)ws; a.w = (const __bf16*)w; a.bias = bias; a.y = (__bf16*)y;
+  a.N = d->N; a.Ho = d->Ho; a.Wo = d->Wo; a.Hp = p.Hp; a.Wp = p.Wp; a.Cout = d->Cout; a.y_pitch = d->y_pitch; a.act = act; a.slope = slope;
+  a.w_row = 49 * 8; a.w_tap = 8; a.flip = 0;
+  return thin4_launch(a, p, st);
+}
+
+// dgrad use: the 7x7 stride-1 conv has <= 4 OUTPUT channels (dY is the thin tensor, pitch 8); the produced tensor dx has Cin channels.
+// Reflect-padded convs produce the PADDED grid (H + 6) x (W + 6) (the full correlation: dY zero-padded by 6), zero-padded ones H x W.
+bool s2p_thin4_dgrad_applicable(const s2p_conv_desc* d, int cout_pad) {
+  if (!(d->dtype == S2P_BF16 && d->groups == 1 && !d->transposed && d->KH == 7 && d->KW == 7 && d->stride == 1 && d->pad == 3 &&
+        d->Cout >= 1 && d->Cout <= 4 && cout_pad == 8 && d->y_pitch == 8 && d->Ho == d->H && d->Wo == d->W))
+    return false;
+  if (d->Cin % 8 || d->Cin < 32 || d->x_pitch % 8) return false;
+  const int e = d->reflect ? 6 : 0;
+  return (long long)d->N * (d->H + e + 6) * (d->W + e + 8) * 8 < (1ll << 31) && (long long)d->N * (d->H + e) * (d->W + e) < (1ll << 31) - 64;
+}
+size_t s2p_thin4_dgrad_ws_bytes(const s2p_conv_desc* d) {
+  const int e = d->reflect ? 6 : 0;
+  return (size_t)d->N * (d->H + e + 6) * (d->W + e + 8) * 8;
+}
+int s2p_thin4_dgrad(const s2p_conv_desc* d, const void* dy, const void* w_bwd, void* dx, int cout_pad, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!ws || ws_bytes < s2p_thin4_dgrad_ws_bytes(d)) S2P_FAIL(-1, "s2p_conv2d_dgrad: this 7x7 thin-output conv needs %zu bytes of workspace (s2p_conv2d_dgrad_workspace)", s2p_thin4_dgrad_ws_bytes(d));
+  const int e = d->reflect ? 6 : 0;                   // produced grid: (H + e) x (W + e); dY padded by 3 + e / 2 ... = (6 | 3) on every side
+  const int pad = d->reflect ? 6 : 3;
+  Pad4Args p{(const __bf16*)dy, (__bf16*)ws, d->N, d->H, d->W, d->y_pitch, d->H + e + 6, d->W + e + 8, pad, 0};
+  Thin4Args a{};
+  a.xp = (const __bf16*)ws; a.w = (const __bf16*)w_bwd; a.bias = nullptr; a.y = (__bf16*)dx;
+  a.N = d->N; a.Ho = d->H + e; a.Wo = d->W + e; a.Hp = p.Hp; a.Wp = p.Wp; a.Cout = d->Cin; a.y_pitch = d->x_pitch; a.act = S2P_ACT_NONE; a.slope = 0.f;
+  a.w_row = 49 * cout_pad; a.w_tap = cout_pad; a.flip = 1;
+  return thin4_launch(a, p, st);
+}

@@ -90,7 +90,7 @@ class ConvGeom:
         Ho, Wo = self.out_hw(H, W)
         return ConvDesc(dtype_id(dtype), N, H, W, cin_pad, x_pitch, Ho, Wo, self.cout, y_pitch,
                         self.k, self.k, self.stride, self.pad, int(self.transposed), int(self.reflect),
-                        self.groups, self.x_gstride, self.y_gstride)
+                        self.groups, self.x_gstride, self.y_gstride, self.cin if self.groups == 1 else 0)
 
 
 def conv_fwd(geom, x, w_fwd, bias, cin_pad, y_pitch=None, act=ACT_NONE, slope=0.2, aux=None, epi=EPI_STORE,
@@ -146,9 +146,11 @@ def conv_dgrad(geom, dy, w_bwd, x_shape, cin_pad, aux=None, epi=EPI_STORE, aux_a
     if geom.reflect:
         p = geom.pad
         dxp = torch.empty((N, H + 2 * p, W + 2 * p, xp), dtype=dy.dtype, device=dy.device)
+        need = lib().s2p_conv2d_dgrad_workspace(ctypes.byref(d))
+        ws = torch.empty(need, dtype=torch.uint8, device=dy.device) if need else None
         pr = _Prof("dgrad", geom, N, H, W, dy.dtype)
-        check(lib().s2p_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(w_bwd), None, None, ptr(dxp), EPI_STORE, ACT_NONE, 0.0,
-                                     stream()), "s2p_conv2d_dgrad")
+        check(lib().s2p_conv2d_dgrad_ws(ctypes.byref(d), ptr(dy), ptr(w_bwd), None, None, ptr(dxp), EPI_STORE, ACT_NONE, 0.0,
+                                        ptr(ws), need, stream()), "s2p_conv2d_dgrad")
         pr.done()
         dx = torch.empty((N, H, W, xp), dtype=dy.dtype, device=dy.device)
         check(lib().s2p_reflect_pad_bwd(dtype_id(dy.dtype), ptr(dxp), N, H, W, xp, p, ptr(dx), stream()),

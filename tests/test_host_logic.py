@@ -46,7 +46,7 @@ def test_product_library_reads_no_environment():
 
 def test_struct_layouts_match_header():
     import ctypes
-    assert ctypes.sizeof(_lib.ConvDesc) == 19 * 4
+    assert ctypes.sizeof(_lib.ConvDesc) == 20 * 4
     assert ctypes.sizeof(_lib.PackJob) == 56      # 3 pointers + 7 int32, padded to 8-byte alignment (same in C)
 
 
