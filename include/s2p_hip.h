@@ -29,7 +29,7 @@ extern "C" {
 /* the library is built with -fvisibility=hidden: only the entry points declared here are exported */
 #pragma GCC visibility push(default)
 
-#define S2P_VERSION 116
+#define S2P_VERSION 117
 
 enum { S2P_F32 = 0, S2P_BF16 = 1 };
 enum { S2P_ACT_NONE = 0, S2P_ACT_RELU = 1, S2P_ACT_LRELU = 2, S2P_ACT_TANH = 3, S2P_ACT_SWISH = 4 };
@@ -303,6 +303,11 @@ int s2p_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
  * can be captured in a hipGraph and replayed                                             */
 int s2p_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                       float beta2, float eps, int* step_dev, float grad_scale, void* stream);
+/* the same update of a RANGE of a flat buffer; tick != 0 increments the device step counter first.  One optimizer step
+ * applied in several launches (the first with tick = 1, the others with tick = 0: they read the counter the first one
+ * wrote, so order them behind it) -- e.g. the part of a gradient buffer that is final early, under the rest of the backward */
+int s2p_adam_step_dev_part(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                           float beta2, float eps, int* step_dev, float grad_scale, int tick, void* stream);
 /* one packing job: src fp32 [R][T][C] (channels-last master weight: R rows, T taps, C
  * channels) -> dst_fwd[r][t][c] (row length T*Cpad, zero pad c>=C)  and/or
  * dst_bwd[c][t][r_off + r] (row length T*Rrow; untouched elements must be pre-zeroed)    */

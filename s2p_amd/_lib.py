@@ -103,6 +103,7 @@ SIGNATURES = {
     "s2p_ensemble_head": [_P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, _P,
                           _P, _P, _P],
     "s2p_adam_step_dev": [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, _P, c_float, _P],
+    "s2p_adam_step_dev_part": [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, _P, c_float, c_int, _P],
     "s2p_pack_weights": [_P, c_int, c_int, _P],
     "s2p_act_bwd": [c_int, _P, _P, c_int64, c_int, c_float, _P, _P],
     "s2p_scale": [c_int, _P, c_int64, _P, _P],
@@ -137,7 +138,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the export is missing
             fn.argtypes = args
             fn.restype = _RESTYPE.get(name, c_int)
-        if L.s2p_version() < 116:
+        if L.s2p_version() < 117:
             raise RuntimeError("libs2p_hip.so is older than this package")
         _lib = L
     return _lib

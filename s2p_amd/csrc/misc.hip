@@ -539,14 +539,18 @@ __global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, lo
     }
   }
 }
-extern "C" int s2p_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int* step_dev, float grad_scale, void* stream) {
+extern "C" int s2p_adam_step_dev_part(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int* step_dev, float grad_scale, int tick, void* stream) {
   if (!p || !g || !m || !v || !step_dev) S2P_FAIL(-1, "s2p_adam_step_dev: bad argument");
+  if (n <= 0) return 0;
   long long n4 = (n + 3) / 4;
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_dev);
+  if (tick) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_dev);
   hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for(n4, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, (long long)n,
                      lr, beta1, beta2, eps, (const int*)step_dev, grad_scale);
   S2P_CHECK_LAUNCH("adam_dev_kernel");
   return 0;
+}
+extern "C" int s2p_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int* step_dev, float grad_scale, void* stream) {
+  return s2p_adam_step_dev_part(p, g, m, v, n, lr, beta1, beta2, eps, step_dev, grad_scale, 1, stream);
 }
 
 // ---- weight packing: fp32 channels-last master [R][T][C] -> compute dtype, both GEMM orientations ----------

@@ -114,6 +114,8 @@ class S2PGenerator(BaseNetwork):
             c //= 2
         self.out = _Conv(c, 3, 7, bias=True)
         self.on_early_grads = None          # optional callable, see bwd_nhwc
+        self.on_tail_final = None           # optional callable: runs (on the weight-gradient stream) once the early-complete tail of the
+                                            # flat gradient is final -- the one-rank trainer applies that range's Adam update there
 
     @property
     def early_grad_offset(self):
@@ -440,6 +442,14 @@ class S2PGenerator(BaseNetwork):
             side_wgrads(wjobs, gb_wgrad(0, rest - 1) if rest > 0 else None)
         else:
             side_wgrads(wjobs, lambda: L["gb"].wgrad(actv, dgb_all))
+        if self.on_tail_final is not None:
+            # one rank: this step's Adam update of the tail (87 % of the parameters) runs here, behind the last weight gradients on their
+            # stream and under the rest of the backward, instead of alone on the chip after it (the optimizer then finishes the head)
+            if ws is not None:
+                with torch.cuda.stream(ws):
+                    self.on_tail_final()
+            else:
+                self.on_tail_final()
         # every gradient of the flat buffer's tail [early_grad_offset, end) is final once these are done (data-parallel hook:
         # the trainer starts the last bucket's all-reduce here, under the rest of this backward; a graph segment ends at the
         # hook, so the side stream re-joins first)

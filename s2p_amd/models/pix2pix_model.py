@@ -30,6 +30,11 @@ class FlatAdam:
     def step(self):
         self.net.store.adam_step(self.param_groups[0]["lr"], self.betas[0], self.betas[1], self.eps, self.grad_scale)
 
+    def step_early(self, start):
+        """This step's update of the flat range [start, end), whose gradients are already final (called from inside the backward,
+        on a side stream); `step()` then finishes [0, start) and repacks."""
+        self.net.store.adam_step_early(start, self.param_groups[0]["lr"], self.betas[0], self.betas[1], self.eps, self.grad_scale)
+
     def state_dict(self):
         return dict(lr=self.param_groups[0]["lr"], **self.net.store.optimizer_state())
 

@@ -505,6 +505,12 @@ def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, step_dev, grad_scale=1.0):
                                   grad_scale, stream()), "s2p_adam_step_dev")
 
 
+def adam_step_dev_part(p, g, m, v, lr, beta1, beta2, eps, step_dev, grad_scale=1.0, tick=True):
+    """One optimizer step applied to a RANGE (views of the flat buffers); the first part ticks the device step counter."""
+    check(lib().s2p_adam_step_dev_part(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, ptr(step_dev),
+                                       grad_scale, int(tick), stream()), "s2p_adam_step_dev_part")
+
+
 def u8_to_nhwc(x_u8, dtype, pitch):
     """uint8 NHWC frames [N,H,W,C] on the device -> compute-dtype NHWC in [-1,1], zero-padded to `pitch` channels."""
     N, H, W, C = x_u8.shape

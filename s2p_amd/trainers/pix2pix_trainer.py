@@ -24,6 +24,10 @@ from ..models.pix2pix_model import Pix2PixModel
 from .. import parallel
 
 
+EARLY_ADAM = False      # one rank: the generator's Adam update of the early-complete tail under the rest of the backward instead of after it.
+                        # Off: same-box A/B 8.957 (on) vs 8.939 ms/step (off) -- the update only trades HBM time with the backward's own passes
+
+
 class Pix2PixTrainer:
     def __init__(self, opt):
         self.opt = opt
@@ -127,7 +131,14 @@ class Pix2PixTrainer:
         self.pix2pix_model.before_netD = self._wait_D_update if multi else None
         g_losses, generated = self.pix2pix_model(data, mode="generator")
         self.pix2pix_model.before_netD = None
-        self._backward(g_losses)           # multi-rank: the tail all-reduce is launched from inside (on_early_grads)
+        netG = self.pix2pix_model.netG
+        if not multi and EARLY_ADAM:
+            # one rank: Adam on the early-complete tail of the flat buffer from inside the backward (S2PGenerator.on_tail_final)
+            netG.on_tail_final = lambda: self.optimizer_G.step_early(netG.early_grad_offset)
+        try:
+            self._backward(g_losses)       # multi-rank: the bucket all-reduces are launched from inside (on_early_grads)
+        finally:
+            netG.on_tail_final = None
         if multi:
             self._finish_G_exchange()
         self.optimizer_G.step()

@@ -510,6 +510,35 @@ def test_trainer_steps_and_checkpoint(hip_device, tmp_path):
     assert torch.equal(ck["netG"]["out.weight"], w1)
 
 
+def test_early_adam_of_the_gradient_tail_is_the_same_update(hip_device, tmp_path):
+    """Pix2PixTrainer.EARLY_ADAM (s2p_adam_step_dev_part from a hook inside the generator's backward: the early-complete tail of the
+    flat buffer is updated under the rest of the backward, the head afterwards) must give bit for bit the parameters, moments and
+    step counter of the single full-buffer launch."""
+    from s2p_amd.trainers import pix2pix_trainer as T
+    prev, state, real = make_inputs(2, 84, 84, 17, seed=6)
+    data = dict(prev_image=prev.cuda(), state=state.cuda(), image=real.cuda())
+    out = {}
+    for early in (False, True):
+        T.EARLY_ADAM = early
+        try:
+            opt = TrainOptions().parse(["--env_type", "cheetah", "--batchSize", "2", "--precision", "bf16", "--gpu_ids", "0",
+                                        "--checkpoints_dir", str(tmp_path)], quiet=True)
+            torch.manual_seed(7)
+            tr = T.Pix2PixTrainer(opt)
+            for _ in range(2):
+                tr.run_generator_one_step(data); tr.run_discriminator_one_step(data)
+            torch.cuda.synchronize()
+            st = tr.pix2pix_model.netG.store
+            out[early] = (st.master.clone(), st.m.clone(), st.v.clone(), int(st.step_dev.item()))
+        finally:
+            T.EARLY_ADAM = False
+    a, b = out[False], out[True]
+    assert a[3] == b[3] == 2
+    for x, y in zip(a[:3], b[:3]):
+        assert torch.equal(x, y)
+    assert float(a[1].abs().max()) > 0
+
+
 def test_trainer_step_matches_oracle_adam(hip_device, tmp_path):
     """One full fp32 trainer G step (losses -> backward -> fused Adam on the flat buffer): the updated master weights against
     the oracle's gradients (taken with the HIP step's branches) pushed through the oracle's Adam restatement."""
