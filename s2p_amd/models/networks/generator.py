@@ -33,6 +33,8 @@ GB_GROUP_MAJOR = True    # the 12 gamma|beta planes (and their gradients) as [12
 GB_WGRAD_CHUNKED = True  # with the data-parallel exchange on: the gamma/beta heads' weight gradients follow the ResBlk batches (4 norms per batch)
                          # instead of one 12-group launch at the end, so 2/3 of the gradient is in flight before the last weight-gradient launch.
                          # On one rank the single launch stays: same-box A/B 8.907 (one launch) vs 8.947 ms/step (three)
+DEC_WGRAD_SIDE = False   # the output / up convs' weight gradients on the weight-gradient stream beside the decoder's backward chain.
+                         # Off: same-box A/B 8.980 (side stream) vs 8.942 ms/step -- as in round 3, co-running kernels only trade CUs
 COND_SIDE = True         # backward of the image-conditioning branch on its own stream, concurrent with the encoder backward
 
 
@@ -351,15 +353,29 @@ class S2PGenerator(BaseNetwork):
         """Backward from d(loss)/d(out) (NHWC).  All parameter gradients are accumulated into the flat grad buffer."""
         L, C, nh = self.lay, self.c_mid, self.nhidden
         out = ctx["out"]
+        main = torch.cuda.current_stream()
+        ws0 = self._wgrad_stream() if (DEC_WGRAD_SIDE and WGRAD_SIDE and not ops.SERIALIZE) else None
+
+        def dec_wgrad(layer, x, dy):
+            """Decoder weight gradients on the weight-gradient stream: the decoder's backward is a serial chain of short launches
+            (dgrad -> norm backward -> dgrad ...) and these do not feed it."""
+            if ws0 is None:
+                layer.wgrad(x, dy)
+                return
+            stepgraph.fork(ws0, main)
+            x.record_stream(ws0); dy.record_stream(ws0)
+            with torch.cuda.stream(ws0):
+                layer.wgrad(x, dy)
+
         dpre = ops.act_bwd(d_out, out, ACT_TANH)
-        L["out"].wgrad(ctx["last"], dpre)
+        dec_wgrad(L["out"], ctx["last"], dpre)
         dx = L["out"].dgrad(dpre, ctx["last"].shape)
         c = self.ngf
         for i in reversed(range(self.n_down)):
             xin, u, s, a = ctx["dec"][i]
             cc = u.shape[3]
             du = ops.in_bwd(dx, u, cc, s, act=ACT_RELU)
-            L[f"up{i}"].wgrad(xin, du)
+            dec_wgrad(L[f"up{i}"], xin, du)
             dx = L[f"up{i}"].dgrad(du, xin.shape)
         gb_all, st_all = ctx["gb_all"], ctx["st_all"]
         dgb_all = torch.empty_like(gb_all)
@@ -371,7 +387,6 @@ class S2PGenerator(BaseNetwork):
         # With WGRAD_SIDE they go to a side stream in batches of WGRAD_CHUNK_BLOCKS blocks while the chain is still running:
         # the chain alternates MFMA-bound convs (442 workgroups on 512 slots) with HBM-bound MAT backward passes, and the
         # weight-gradient workgroups take the MFMA time those leave idle.
-        main = torch.cuda.current_stream()
         ws = self._wgrad_stream() if (WGRAD_SIDE and not ops.SERIALIZE) else None
 
         def side_wgrads(jobs, extra=None):
