@@ -1300,7 +1300,7 @@ static int launch_fast(GatherArgs& a, int groups, hipStream_t st) {
     PlaneGProblem pr{a.M / (a.Qh * a.Qw), a.Hi, a.Wi, a.Ho, a.Wo, a.Cin, a.Cout, a.Cst, a.x_pitch, a.y_pitch, a.istride, a.T, a.tap};
     PlaneGArgs p{};
     if (s2p_conv_planeg_setup(pr, p)) {
-      const bool fuse = a.mat && !a.mat->gb && a.act == S2P_ACT_NONE && a.epi != S2P_EPI_MUL_ACTGRAD;
+      const bool fuse = a.mat && p.nbands == 1 && !a.mat->gb && a.act == S2P_ACT_NONE && a.epi != S2P_EPI_MUL_ACTGRAD;
       if (fuse) *a.mat_done = 1;
       if (a.plan) return 0;                                // no scratch
       p.x = a.x; p.w = a.w; p.bias = a.bias; p.aux = a.aux; p.aux2 = a.aux2; p.y = a.y;

@@ -35,23 +35,27 @@ constexpr int PG_ERS = 144;                  // epilogue staging row: 64 co x 2 
 // PPW pieces per wave and plane go out two per pair-step (all of them in the one slot when T == 4).
 template <int T, int PPW> struct PgSched {
   static constexpr bool EARLY1 = T >= 6;
-  static constexpr int NS = (PPW + 1) / 2;                                   // pair-steps used per plane (T >= 6)
   static constexpr int W1_END = EARLY1 ? (T - 2) / 2 - 2 : -1;
   static constexpr int W0_BEG = (T - 3) / 2 + 1, W0_END = T - 3;
-  static constexpr int P0_U0 = EARLY1 ? W0_END + 1 - NS : 1;
-  static_assert(!EARLY1 || (NS <= W1_END + 1 && P0_U0 >= W0_BEG), "plane prefetch does not fit its window");
+  static constexpr int PER1 = EARLY1 ? (PPW + W1_END) / (W1_END + 1) : PPW;              // pieces per pair-step (2 at least: the 3x3 kernel's pace)
+  static constexpr int PER0 = EARLY1 ? (PPW + (W0_END - W0_BEG)) / (W0_END - W0_BEG + 1) : PPW;
+  static constexpr int Q1 = PER1 < 2 ? 2 : PER1, Q0 = PER0 < 2 ? 2 : PER0;
+  static constexpr int NS1 = (PPW + Q1 - 1) / Q1, NS0 = (PPW + Q0 - 1) / Q0;             // pair-steps used per plane
+  static constexpr int P0_U0 = EARLY1 ? W0_END + 1 - NS0 : 1;
+  static_assert(!EARLY1 || (NS1 <= W1_END + 1 && P0_U0 >= W0_BEG), "plane prefetch does not fit its window");
   // buffer (-1: none), first piece, piece count issued in pair-step U
   static constexpr int buf(int U) {
     if (!EARLY1) return U == 1 ? 0 : (U == 3 ? 1 : -1);
-    if (U < NS) return 1;
-    if (U >= P0_U0 && U < P0_U0 + NS) return 0;
+    if (U < NS1) return 1;
+    if (U >= P0_U0 && U < P0_U0 + NS0) return 0;
     return -1;
   }
-  static constexpr int k0(int U) { return !EARLY1 ? 0 : (U < NS ? 2 * U : 2 * (U - P0_U0)); }
+  static constexpr int k0(int U) { return !EARLY1 ? 0 : (U < NS1 ? Q1 * U : Q0 * (U - P0_U0)); }
   static constexpr int cnt(int U) {
     if (buf(U) < 0) return 0;
     if (!EARLY1) return PPW;
-    return PPW - k0(U) < 2 ? PPW - k0(U) : 2;
+    const int q = buf(U) == 1 ? Q1 : Q0;
+    return PPW - k0(U) < q ? PPW - k0(U) : q;
   }
   static constexpr int hs_ahead(int U) { return !EARLY1 ? (U == 1 ? 2 : 3) : (buf(U) == 1 ? 1 : 2); }
 };
@@ -85,14 +89,19 @@ __global__ __launch_bounds__(512) void conv_planeg_kernel(const PlaneGArgs a) {
   const int set = wave >> 2, wq = wave & 3;
   const int q = lane >> 4, l15 = lane & 15;
   const int g = blockIdx.y;
-  int img, cs;
+  // workgroup -> (plane = image x row band, co slab): the nco slabs of one plane run back to back on ONE XCD
+  int pl, cs;
   {
-    const int bid = blockIdx.x, nco = a.nco;
-    if ((a.N & 7) == 0) { const int xcd = bid & 7, k = bid >> 3; cs = k % nco; img = (k / nco) * 8 + xcd; }
-    else { cs = bid % nco; img = bid / nco; }
+    const int bid = blockIdx.x, nco = a.nco, np = a.N * a.nbands;
+    if ((np & 7) == 0) { const int xcd = bid & 7, k = bid >> 3; cs = k % nco; pl = (k / nco) * 8 + xcd; }
+    else { cs = bid % nco; pl = bid / nco; }
   }
+  const int img = pl / a.nbands, band = pl - img * a.nbands;
+  const int r0 = band * a.R;                                   // first produced row of this band (0 when the plane is the whole image)
   const int co_base = cs * 64;
-  const int HW = a.Ho * a.Wo;                                  // produced plane
+  const int rows_here = a.Ho - r0 < a.R ? a.Ho - r0 : a.R;
+  const int HW = rows_here * a.Wo;                             // pixels this workgroup produces
+  const size_t pix0 = (size_t)img * a.Ho * a.Wo + (size_t)r0 * a.Wo;      // index of its first pixel in the produced tensor
 
   const T* xg = (const T*)a.x + (size_t)g * a.x_gstride;
   const T* wg = (const T*)a.w + (size_t)g * a.w_gstride;
@@ -115,7 +124,7 @@ __global__ __launch_bounds__(512) void conv_planeg_kernel(const PlaneGArgs a) {
       const int cp = ii & 1, pg = ii >> 1;
       const int pos = 32 * pg + (lane >> 1);
       const int row = (int)(((float)pos + 0.5f) * rwp), col = pos - row * a.WP;      // exact for pos < 2^20
-      const int yi = row - a.PT, xi = col - a.PL;
+      const int yi = row - a.PT + r0, xi = col - a.PL;      // (bands: stride-1 form only -- produced row r reads gathered rows r - PT ..)
       const bool in = yi >= 0 && yi < a.Hs && xi >= 0 && xi < a.Ws;
       int m = 0;
       if constexpr (S2D) {
@@ -333,13 +342,13 @@ __global__ __launch_bounds__(512) void conv_planeg_kernel(const PlaneGArgs a) {
   if constexpr (MAT == 0) {
     for (int idx = tid; idx < HW * 8; idx += 512) {
       const int row = idx >> 3, ch = idx & 7;
-      const size_t go = ((size_t)img * HW + row) * a.y_pitch + co_base + ch * 8;
+      const size_t go = (pix0 + row) * a.y_pitch + co_base + ch * 8;
       *(u32x4*)(yg + go) = out_chunk(row, ch, go).raw;
     }
   } else if constexpr (MAT == 1) {
     // ---- fused InstanceNorm (+ MAT modulation) + activation of the plane this workgroup owns (conv_plane.hip, MAT == 1) ---------
     const int ch = tid & 7, r0 = tid >> 3;
-    const T* gbb = (GB && a.gb) ? (const T*)a.gb + (size_t)img * HW * a.gb_pitch + co_base + ch * 8 : nullptr;
+    const T* gbb = (GB && a.gb) ? (const T*)a.gb + pix0 * a.gb_pitch + co_base + ch * 8 : nullptr;
     Chunk<T> xv[MAXR], gv[GB ? MAXR : 1], bv[GB ? MAXR : 1];
     if constexpr (GB) {
 #pragma unroll
@@ -357,7 +366,7 @@ __global__ __launch_bounds__(512) void conv_planeg_kernel(const PlaneGArgs a) {
       const int row = r0 + 64 * k;
       xv[k].raw = (u32x4){0u, 0u, 0u, 0u};
       if (row < HW) {
-        const size_t go = ((size_t)img * HW + row) * a.y_pitch + co_base + ch * 8;
+        const size_t go = (pix0 + row) * a.y_pitch + co_base + ch * 8;
         xv[k] = out_chunk(row, ch, go);
         *(u32x4*)(yg + go) = xv[k].raw;
       }
@@ -421,7 +430,7 @@ __global__ __launch_bounds__(512) void conv_planeg_kernel(const PlaneGArgs a) {
       gs[e] = cst[2 * 64 + ch * 8 + e]; bs[e] = cst[3 * 64 + ch * 8 + e];
     }
     const float nns = a.n_act == S2P_ACT_RELU ? 0.f : (a.n_act == S2P_ACT_LRELU ? a.n_slope : 1.f);
-    T* y2 = (T*)a.y2 + (size_t)img * HW * a.y2_pitch + co_base + ch * 8;
+    T* y2 = (T*)a.y2 + pix0 * a.y2_pitch + co_base + ch * 8;
 #pragma unroll
     for (int k = 0; k < MAXR; ++k) {
       const int row = r0 + 64 * k;
@@ -440,8 +449,8 @@ __global__ __launch_bounds__(512) void conv_planeg_kernel(const PlaneGArgs a) {
     // ---- fused backward of InstanceNorm (+ MAT modulation) + activation (conv_plane.hip, MAT == 2): the staged plane (+ the aux
     //      gradient of EPI_ADD, e.g. a feature-matching tap) is dL/d(norm output) for this (image, slab); it never goes to HBM --------
     const int ch = tid & 7, r0 = tid >> 3, lc = co_base + ch * 8;
-    const T* xb = (const T*)a.xn + (size_t)img * HW * a.xn_pitch + lc;
-    const T* gbb = (GB && a.gb) ? (const T*)a.gb + (size_t)img * HW * a.gb_pitch + lc : nullptr;
+    const T* xb = (const T*)a.xn + pix0 * a.xn_pitch + lc;
+    const T* gbb = (GB && a.gb) ? (const T*)a.gb + pix0 * a.gb_pitch + lc : nullptr;
     Chunk<T> xv[MAXR], gv[GB ? MAXR : 1], bv[GB ? MAXR : 1], dv[MAXR];
 #pragma unroll
     for (int k = 0; k < MAXR; ++k) {
@@ -453,7 +462,7 @@ __global__ __launch_bounds__(512) void conv_planeg_kernel(const PlaneGArgs a) {
         if constexpr (GB) {
           if (gbb) { gv[k].raw = *(const u32x4*)(gbb + (size_t)row * a.gb_pitch); bv[k].raw = *(const u32x4*)(gbb + (size_t)row * a.gb_pitch + a.Cout); }
         }
-        dv[k] = out_chunk(row, ch, ((size_t)img * HW + row) * a.y_pitch + lc);      // rows beyond HW stay zero: they add nothing to the sums
+        dv[k] = out_chunk(row, ch, (pix0 + row) * a.y_pitch + lc);      // rows beyond HW stay zero: they add nothing to the sums
       }
     }
     __syncthreads();                                            // the staging rows are dead: LDS is scratch from here on
@@ -513,9 +522,9 @@ __global__ __launch_bounds__(512) void conv_planeg_kernel(const PlaneGArgs a) {
       }
     }
     __syncthreads();
-    T* dxo = (T*)a.y2 + (size_t)img * HW * a.y2_pitch + lc;
-    T* dgo = a.dgb ? (T*)a.dgb + (size_t)img * HW * a.dgb_pitch + lc : nullptr;
-    const T* rsb = a.res ? (const T*)a.res + (size_t)img * HW * a.res_pitch + lc : nullptr;
+    T* dxo = (T*)a.y2 + pix0 * a.y2_pitch + lc;
+    T* dgo = a.dgb ? (T*)a.dgb + pix0 * a.dgb_pitch + lc : nullptr;
+    const T* rsb = a.res ? (const T*)a.res + pix0 * a.res_pitch + lc : nullptr;
 #pragma unroll
     for (int k = 0; k < MAXR; ++k) {
       const int row = r0 + 64 * k;
@@ -551,20 +560,31 @@ namespace {
 struct PgShape { int TY, TX, PB, NPB, S2D; };
 // instantiated shapes: 4x4 stride 1 on planes up to 64 / 192 produced pixels (the 256 -> 512 layers of both scales and their dgrads);
 // 4x4 stride 2 pad 2 in the parity form (2x2 raster taps) on the same tile sizes (128 -> 256 of both scales, 64 -> 128 of the coarser);
-// 3x3 stride 1 on planes of 65..128 produced pixels (VGG conv4_x on 10x10 maps and their dgrads: too small for conv_plane.hip's tile)
-const PgShape PG_SHAPES[] = {{4, 4, 1, 128, 0}, {4, 4, 3, 256, 0}, {2, 2, 1, 128, 1}, {2, 2, 3, 256, 1}, {3, 3, 2, 256, 0}};
+// 3x3 stride 1 on planes of 65..128 produced pixels (VGG conv4_x on 10x10 maps and their dgrads: too small for conv_plane.hip's tile);
+// 3x3 stride 1 on ROW BANDS (up to 448 pixels, 640 raster positions) of larger planes: VGG conv1_2 at 84x84 (5 rows per band),
+// conv2_x at 42x42 (10 rows), the 64x64 ResBlk maps of the 256x256 rollout -- one workgroup per (image, band, 64-channel slab)
+const PgShape PG_SHAPES[] = {{4, 4, 1, 128, 0}, {4, 4, 3, 256, 0}, {2, 2, 1, 128, 1}, {2, 2, 3, 256, 1}, {3, 3, 2, 256, 0}, {3, 3, 7, 640, 0}};
+constexpr int PG_BAND_SHAPE = 5;             // the shape that takes ROW BANDS of planes too large for any whole-plane shape
 }  // namespace
 
 static bool pg_pick_shape(PlaneGArgs& a, int TY, int TX, int s2d) {
   const int HW = a.Ho * a.Wo;
   const int last = (a.Ho - 1 + TY - 1) * a.WP + (a.Wo - 1 + TX - 1);              // last raster position any tap reads
-  a.shape = -1;
+  a.shape = -1; a.R = a.Ho; a.nbands = 1;
   for (int i = 0; i < (int)(sizeof(PG_SHAPES) / sizeof(PG_SHAPES[0])); ++i) {     // (ordered by tile size: the smallest that fits)
     const PgShape& s = PG_SHAPES[i];
     if (s.TY == TY && s.TX == TX && s.S2D == s2d && HW <= 4 * s.PB * 16 && last < s.NPB) { a.shape = i; break; }
   }
   // a plane much smaller than the tile wastes the MFMAs: leave those to the generic kernels
-  return a.shape >= 0 && 2 * HW > 4 * PG_SHAPES[a.shape].PB * 16;
+  if (a.shape >= 0) return 2 * HW > 4 * PG_SHAPES[a.shape].PB * 16;
+  // too large for a whole-plane tile: row bands of the stride-1 form (no fused norm: its statistics span the whole plane)
+  const PgShape& b = PG_SHAPES[PG_BAND_SHAPE];
+  if (s2d || b.TY != TY || b.TX != TX || S2P_DIAG_SWITCH(4)) return false;
+  int R = (b.NPB - TX) / a.WP - (TY - 1);                                        // (R + TY - 1) * WP + TX <= NPB
+  if (R * a.Wo > 4 * b.PB * 16) R = (4 * b.PB * 16) / a.Wo;
+  if (R < 2 || 4 * R * a.Wo < 3 * 4 * b.PB * 16) return false;                    // at least 3/4 of the tile used
+  a.shape = PG_BAND_SHAPE; a.R = R; a.nbands = (a.Ho + R - 1) / R;
+  return true;
 }
 
 bool s2p_conv_planeg_setup(const PlaneGProblem& p, PlaneGArgs& a) {
@@ -626,12 +646,14 @@ static void pg_launch_shape(const PlaneGArgs& a, dim3 grid, hipStream_t st) {
 int s2p_conv_planeg_launch(PlaneGArgs& a, int groups, hipStream_t st) {
   a.nco = a.Cout / 64;
   if (a.gb) S2P_FAIL(-1, "conv_planeg: gamma / beta maps are not instantiated for this kernel family");
-  dim3 grid(a.N * a.nco, groups);
+  if (a.nbands > 1 && a.y2) S2P_FAIL(-1, "conv_planeg: the fused norm needs the whole plane in one workgroup");
+  dim3 grid(a.N * a.nbands * a.nco, groups);
   if (a.shape == 0) pg_launch_shape<4, 4, 1, 128, false>(a, grid, st);
   else if (a.shape == 1) pg_launch_shape<4, 4, 3, 256, false>(a, grid, st);
   else if (a.shape == 2) pg_launch_shape<2, 2, 1, 128, true>(a, grid, st);
   else if (a.shape == 3) pg_launch_shape<2, 2, 3, 256, true>(a, grid, st);
   else if (a.shape == 4) pg_launch_shape<3, 3, 2, 256, false>(a, grid, st);
+  else if (a.shape == 5) pg_launch_shape<3, 3, 7, 640, false>(a, grid, st);
   else S2P_FAIL(-1, "conv_planeg: no kernel instantiated for this shape (s2p_conv_planeg_setup decides)");
   S2P_CHECK_LAUNCH("conv_planeg_kernel");
   return 0;

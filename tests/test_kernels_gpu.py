@@ -73,6 +73,9 @@ CONV_CASES = [
     (64, 64, 3, 1, 1, False, False, 20, 17, 9),    # plane-resident kernel: one co slab, 340-px plane (last blocks padded), N % 8 != 0
     (192, 64, 3, 1, 1, False, False, 21, 21, 2),   # plane-resident kernel: odd number of 64-channel input slabs
     (128, 256, 3, 1, 1, False, False, 21, 20, 72), # plane-resident PAIR kernel (288 tiles > 256, even slab count): two slabs per workgroup
+    (64, 64, 3, 1, 1, False, False, 84, 84, 2),    # VGG conv1_2: row bands of the generalised plane kernel (17 bands of 5 rows, the last one short)
+    (64, 128, 3, 1, 1, False, False, 42, 42, 3),   # VGG conv2_1: 5 bands of 10 rows, two co slabs, N * bands % 8 != 0
+    (128, 128, 3, 1, 1, False, False, 30, 37, 8),  # bands on a ragged plane (11 rows per band), N * bands % 8 == 0: XCD-aware order
     (64, 128, 3, 1, 1, False, False, 19, 21, 131), # ... one pair per image, N % 8 != 0
 ]
 
