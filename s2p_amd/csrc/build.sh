@@ -15,7 +15,7 @@ cd "$(dirname "$0")"
 OUT=libs2p_hip.so; SUF=""; EXTRA=""
 DIAG_SRCS=""
 if [ "$1" = "diag" ]; then OUT=libs2p_hip_diag.so; SUF=".diag"; EXTRA="-DS2P_DIAG_BUILD"; DIAG_SRCS="diag_probe.hip"; shift; fi
-SRCS="conv_igemm.hip conv_plane.hip conv_planeg.hip wgrad_igemm.hip wgrad_slab.hip wgrad_head.hip linear_small.hip norm.hip misc.hip thin_conv.hip thin_rows.hip metrics.hip"
+SRCS="conv_igemm.hip conv_plane.hip conv_planeg.hip wgrad_igemm.hip wgrad_slab.hip wgrad_slabg.hip wgrad_head.hip linear_small.hip norm.hip misc.hip thin_conv.hip thin_rows.hip metrics.hip"
 NOPK="-Xclang -target-feature -Xclang -packed-fp32-ops"
 newest=$(ls -t $SRCS $DIAG_SRCS s2p_common.h conv_plane.h conv_planeg.h ../../include/s2p_hip.h build.sh | head -1)
 if [ -z "$FORCE" ] && [ -f "$OUT" ] && [ "$OUT" -nt "$newest" ]; then echo "up to date: $(pwd)/$OUT"; exit 0; fi

@@ -165,6 +165,11 @@ bool s2p_thin4_dgrad_applicable(const s2p_conv_desc* d, int cout_pad);
 size_t s2p_thin4_dgrad_ws_bytes(const s2p_conv_desc* d);
 int s2p_thin4_dgrad(const s2p_conv_desc* d, const void* dy, const void* w_bwd, void* dx, int cout_pad, void* ws, size_t ws_bytes, hipStream_t st);
 // PatchGAN logit heads, Cout = 1 (wgrad_head.hip)
+// wgrad_slabg.hip: padded-raster weight gradient of the strided / 4x4 convolutions (fixed-order partial reduce; needs its workspace)
+bool s2p_wgrad_slabg_supported(const s2p_conv_desc* d, int cin_real, int cout_real);
+size_t s2p_wgrad_slabg_workspace(const s2p_conv_desc* d, int cin_real, int cout_real);
+int s2p_wgrad_slabg(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, float* db, int cin_real, int cout_real,
+                    void* workspace, size_t workspace_bytes, hipStream_t st);
 bool s2p_head_wgrad_supported(const s2p_conv_desc* d, int cin_real, int cout_real);
 size_t s2p_head_wgrad_workspace(const s2p_conv_desc* d);
 bool s2p_head_fwd_applicable(const s2p_conv_desc* d);

@@ -547,12 +547,14 @@ extern "C" size_t s2p_conv2d_wgrad_workspace(const s2p_conv_desc* d, int cin_rea
     const size_t t = s2p_thin_wgrad_ws_bytes(d, cin_real);
     return t ? ws_align(t) + wgrad_bias_ws_bytes(d, cout_real) : 0;
   }
+  // strided / 4x4 layers: padded-raster slab kernel (wgrad_slabg.hip); the scratch serves either kernel
+  const size_t sg = s2p_wgrad_slabg_workspace(d, cin_real, cout_real);
   bool dense = true;
   WgradArgs a{};
-  if (!wgrad_dma_plan(d, cin_real, cout_real, a, dense)) return 0;
+  if (!wgrad_dma_plan(d, cin_real, cout_real, a, dense)) return sg;
   const size_t w = wgrad_dma_ws_bytes(d, cin_real, cout_real, nullptr);
-  if (dense) return w;                                   // fused bias gradient
-  return ws_align(w) + wgrad_bias_ws_bytes(d, cout_real);
+  const size_t g = dense ? w : ws_align(w) + wgrad_bias_ws_bytes(d, cout_real);      // dense: fused bias gradient
+  return g > sg ? g : sg;
 }
 
 extern "C" int s2p_conv2d_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, float* db,
@@ -586,6 +588,9 @@ extern "C" int s2p_conv2d_wgrad_ws(const s2p_conv_desc* d, const void* x, const 
     return s2p_thin_wgrad(d, x, dy, dw, cin_real, det ? workspace : nullptr, det ? tw : 0, (hipStream_t)stream);
   }
   hipStream_t st = (hipStream_t)stream;
+  if (workspace && s2p_wgrad_slabg_supported(d, cin_real, cout_real) &&
+      workspace_bytes >= s2p_wgrad_slabg_workspace(d, cin_real, cout_real))
+    return s2p_wgrad_slabg(d, x, dy, dw, db, cin_real, cout_real, workspace, workspace_bytes, st);
   {
     // bf16, tensors < 2 GiB: LDS-DMA kernels.  With a workspace (s2p_conv2d_wgrad_workspace) the split units store
     // partial tiles and a second kernel adds them in unit order: no atomics, bitwise reproducible, and no 16-fold

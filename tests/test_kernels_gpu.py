@@ -522,6 +522,12 @@ def test_conv_small_map_splitk(hip_device, case):
     (256, 512, 4, 1, 2, False, 7, 7, 8),       # PatchGAN 256->512: 128 tiles, 8 units
     (128, 64, 3, 2, 1, True, 12, 12, 4),       # up conv (transposed form, no bias gradient)
     (64, 128, 3, 2, 1, False, 20, 20, 4),      # down conv
+    # the padded-raster kernel of the 4x4 layers (csrc/wgrad_slabg.hip) at the sizes of the train step
+    (64, 128, 3, 2, 1, False, 84, 84, 2),      # encoder at the real size (implicit GEMM: the 3x3 stride-2 layers stay there)
+    (256, 128, 3, 2, 1, True, 21, 21, 3),      # decoder (transposed form) at the real size
+    (64, 128, 4, 2, 2, False, 43, 43, 3),      # PatchGAN 4x4 stride 2 on an odd size: four classes of 4 taps, parity-1 planes one short
+    (128, 256, 4, 2, 2, False, 21, 23, 2),     # ... H != W
+    (256, 512, 4, 1, 2, False, 12, 12, 3),     # PatchGAN 4x4 stride 1, pad 2: two classes of 8 taps, dY one row / column larger than x
 ])
 def test_conv_wgrad_split_units_deterministic(hip_device, case):
     """s2p_conv2d_wgrad_ws: the K-split units of the LDS-DMA weight-gradient kernel store partial tiles and a second
