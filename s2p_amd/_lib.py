@@ -10,7 +10,7 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.environ.get("S2P_LIB") or os.path.join(_HERE, "csrc", "libs2p_hip.so")     # S2P_LIB: A/B a second build
+_SO = os.path.join(_HERE, "csrc", "libs2p_hip.so")     # (tools/uselib.py points this at a second build for an A/B; no environment variable is read here)
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SWISH = 0, 1, 2, 3, 4

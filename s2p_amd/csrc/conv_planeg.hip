@@ -23,6 +23,9 @@ __device__ __forceinline__ void pg_dma16(i32x4 rsrc, unsigned lds_dst, int voffs
                :: "v"(voffset), "s"(rsrc), "s"(lds_dst), "s"(soffset) : "memory", "m0");
 }
 
+#ifndef PG_OCC4_ALL
+#define PG_OCC4_ALL 0      // 1 (timing builds): also the 4x4 / parity-form 192-pixel shapes are limited to 128 VGPRs (two workgroups per CU; spills)
+#endif
 namespace {
 constexpr int PG_WST = 4096;                 // one weight stage: [2 pairs][64 co][32 B]
 constexpr int PG_ERS = 144;                  // epilogue staging row: 64 co x 2 B + 16
@@ -64,7 +67,7 @@ template <int T, int PPW> struct PgSched {
 // MAT: 0 plain conv, 1 + InstanceNorm (+ MAT modulation) + activation of the output plane, 2 + backward of the norm that FED this
 // dgrad's forward conv.  GB: gamma / beta maps may be present (false: plain InstanceNorm, no registers spent on them).
 template <int TY, int TX, int PB, int NPB, int RING, int MAT, bool S2D, bool GB>
-__global__ __launch_bounds__(512) void conv_planeg_kernel(const PlaneGArgs a) {
+__global__ __launch_bounds__(512, ((PB <= 3 && (TY == 3 || PG_OCC4_ALL)) ? 4 : 2)) void conv_planeg_kernel(const PlaneGArgs a) {
   typedef __bf16 T;
   constexpr int NTAP = TY * TX, NSTEP = 2 * NTAP;
   static_assert(NSTEP % RING == 0 && RING % 2 == 0 && RING >= 6, "ring must divide the steps of an iteration");
@@ -563,28 +566,39 @@ struct PgShape { int TY, TX, PB, NPB, S2D; };
 // 3x3 stride 1 on planes of 65..128 produced pixels (VGG conv4_x on 10x10 maps and their dgrads: too small for conv_plane.hip's tile);
 // 3x3 stride 1 on ROW BANDS (up to 448 pixels, 640 raster positions) of larger planes: VGG conv1_2 at 84x84 (5 rows per band),
 // conv2_x at 42x42 (10 rows), the 64x64 ResBlk maps of the 256x256 rollout -- one workgroup per (image, band, 64-channel slab)
-const PgShape PG_SHAPES[] = {{4, 4, 1, 128, 0}, {4, 4, 3, 256, 0}, {2, 2, 1, 128, 1}, {2, 2, 3, 256, 1}, {3, 3, 2, 256, 0}, {3, 3, 7, 640, 0}};
+// With 64 input channels (18 K steps) the fixed part of a workgroup -- first plane fetch, accumulator exchange, staging,
+// store -- is as long as its loop: those layers take 192-pixel bands (74 KB of LDS: two workgroups per CU, one's fixed part under the
+// other's loop) instead of 448-pixel ones (112 KB, one per CU).
+const PgShape PG_SHAPES[] = {{4, 4, 1, 128, 0}, {4, 4, 3, 256, 0}, {2, 2, 1, 128, 1}, {2, 2, 3, 256, 1}, {3, 3, 2, 256, 0}, {3, 3, 7, 640, 0},
+                             {3, 3, 3, 384, 0}};
 constexpr int PG_BAND_SHAPE = 5;             // the shape that takes ROW BANDS of planes too large for any whole-plane shape
+constexpr int PG_BAND_SHAPE_SHORTK = 6;      // ... when the K loop is short (Cin = 64; measured: 128 -> 128 at 42x42 is 2 % faster on the large bands)
 }  // namespace
 
-static bool pg_pick_shape(PlaneGArgs& a, int TY, int TX, int s2d) {
+static bool pg_pick_shape(PlaneGArgs& a, int TY, int TX, int s2d, int Cin) {
   const int HW = a.Ho * a.Wo;
   const int last = (a.Ho - 1 + TY - 1) * a.WP + (a.Wo - 1 + TX - 1);              // last raster position any tap reads
   a.shape = -1; a.R = a.Ho; a.nbands = 1;
   for (int i = 0; i < (int)(sizeof(PG_SHAPES) / sizeof(PG_SHAPES[0])); ++i) {     // (ordered by tile size: the smallest that fits)
     const PgShape& s = PG_SHAPES[i];
-    if (s.TY == TY && s.TX == TX && s.S2D == s2d && HW <= 4 * s.PB * 16 && last < s.NPB) { a.shape = i; break; }
+    if (i != PG_BAND_SHAPE_SHORTK && s.TY == TY && s.TX == TX && s.S2D == s2d && HW <= 4 * s.PB * 16 && last < s.NPB) { a.shape = i; break; }
   }
   // a plane much smaller than the tile wastes the MFMAs: leave those to the generic kernels
   if (a.shape >= 0) return 2 * HW > 4 * PG_SHAPES[a.shape].PB * 16;
   // too large for a whole-plane tile: row bands of the stride-1 form (no fused norm: its statistics span the whole plane)
-  const PgShape& b = PG_SHAPES[PG_BAND_SHAPE];
-  if (s2d || b.TY != TY || b.TX != TX || S2P_DIAG_SWITCH(4)) return false;
-  int R = (b.NPB - TX) / a.WP - (TY - 1);                                        // (R + TY - 1) * WP + TX <= NPB
-  if (R * a.Wo > 4 * b.PB * 16) R = (4 * b.PB * 16) / a.Wo;
-  if (R < 2 || 4 * R * a.Wo < 3 * 4 * b.PB * 16) return false;                    // at least 3/4 of the tile used
-  a.shape = PG_BAND_SHAPE; a.R = R; a.nbands = (a.Ho + R - 1) / R;
-  return true;
+  if (s2d || S2P_DIAG_SWITCH(4)) return false;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int bi = pass == 0 ? PG_BAND_SHAPE_SHORTK : PG_BAND_SHAPE;
+    if (pass == 0 && (Cin > 64 || S2P_DIAG_SWITCH(8))) continue;
+    const PgShape& b = PG_SHAPES[bi];
+    if (b.TY != TY || b.TX != TX) continue;
+    int R = (b.NPB - TX) / a.WP - (TY - 1);                                      // (R + TY - 1) * WP + TX <= NPB
+    if (R * a.Wo > 4 * b.PB * 16) R = (4 * b.PB * 16) / a.Wo;
+    if (R < 2 || 4 * R * a.Wo < 3 * 4 * b.PB * 16) continue;                      // at least 3/4 of the tile used
+    a.shape = bi; a.R = R; a.nbands = (a.Ho + R - 1) / R;
+    return true;
+  }
+  return false;
 }
 
 bool s2p_conv_planeg_setup(const PlaneGProblem& p, PlaneGArgs& a) {
@@ -608,7 +622,7 @@ bool s2p_conv_planeg_setup(const PlaneGProblem& p, PlaneGArgs& a) {
     a.PT = 1; a.PL = 1;
     const int PR = p.Wo - a.Ws > 0 ? p.Wo - a.Ws : 0;
     a.WP = a.Ws + (PR > 1 ? PR : 1);
-    return pg_pick_shape(a, 2, 2, 1);
+    return pg_pick_shape(a, 2, 2, 1, p.Cin);
   }
   if (p.istride != 1) return false;
   if (p.T < 1 || p.T > 16) return false;
@@ -632,7 +646,7 @@ bool s2p_conv_planeg_setup(const PlaneGProblem& p, PlaneGArgs& a) {
   // overhang) zero columns, which serve as the right pad of a row AND the left pad of the next one
   const int PR = p.Wo - p.Wi + dx1 > 0 ? p.Wo - p.Wi + dx1 : 0;
   a.WP = p.Wi + (a.PL > PR ? a.PL : PR);
-  return pg_pick_shape(a, TY, TX, 0);
+  return pg_pick_shape(a, TY, TX, 0, p.Cin);
 }
 
 template <int TY, int TX, int PB, int NPB, bool S2D>
@@ -654,6 +668,7 @@ int s2p_conv_planeg_launch(PlaneGArgs& a, int groups, hipStream_t st) {
   else if (a.shape == 3) pg_launch_shape<2, 2, 3, 256, true>(a, grid, st);
   else if (a.shape == 4) pg_launch_shape<3, 3, 2, 256, false>(a, grid, st);
   else if (a.shape == 5) pg_launch_shape<3, 3, 7, 640, false>(a, grid, st);
+  else if (a.shape == 6) pg_launch_shape<3, 3, 3, 384, false>(a, grid, st);
   else S2P_FAIL(-1, "conv_planeg: no kernel instantiated for this shape (s2p_conv_planeg_setup decides)");
   S2P_CHECK_LAUNCH("conv_planeg_kernel");
   return 0;

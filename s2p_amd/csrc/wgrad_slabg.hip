@@ -232,6 +232,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_slabg_kernel(const WgSlabGArgs a
   const int split = rem / a.tiles_per_cls, tile = rem - split * a.tiles_per_cls;
   const int T = a.cls_T[cls];
   if (T == 8) sg_body<8, NXI>(a, smem, cls, tile, split);
+#ifdef S2P_DIAG_BUILD
+  else if (T == 2) sg_body<2, NXI>(a, smem, cls, tile, split);
+  else if (T == 1) sg_body<1, NXI>(a, smem, cls, tile, split);
+#endif
   else sg_body<4, NXI>(a, smem, cls, tile, split);
 }
 
@@ -295,7 +299,9 @@ static bool sg_plan(const s2p_conv_desc* d, int cin_real, int cout_real, WgSlabG
   if (!d || d->dtype != S2P_BF16 || d->reflect || d->groups != 1 || d->KH != d->KW) return false;
   if (d->Cin % 64 || d->Cout % 64 || cin_real != d->Cin || cout_real != d->Cout) return false;
   const int K = d->KH, s = d->stride, pad = d->pad;
-  if (K != 4 || pad != 2 || (s != 1 && s != 2) || (s == 1 && d->transposed)) return false;
+  const bool k4 = K == 4 && pad == 2 && (s == 2 || (s == 1 && !d->transposed));
+  const bool k3 = K == 3 && pad == 1 && s == 2 && S2P_DIAG_SWITCH(6);      // diagnostics build only: the encoder / decoder convs
+  if (!k4 && !k3) return false;
   int Ca, Cb;
   if (!d->transposed) { a.Ha = d->Ho; a.Wa = d->Wo; a.Hb = d->H; a.Wb = d->W; Ca = d->Cout; Cb = d->Cin; a.a_pitch = d->y_pitch; a.b_pitch = d->x_pitch; }
   else { a.Ha = d->H; a.Wa = d->W; a.Hb = d->Ho; a.Wb = d->Wo; Ca = d->Cin; Cb = d->Cout; a.a_pitch = d->x_pitch; a.b_pitch = d->y_pitch; }
@@ -335,7 +341,7 @@ static bool sg_plan(const s2p_conv_desc* d, int cin_real, int cout_real, WgSlabG
   for (int i = 0; i < ncand; ++i) {
     const int c = order[i];
     if (!cnt[c]) continue;
-    if (cnt[c] != 4 && cnt[c] != 8) return false;
+    if (cnt[c] != 4 && cnt[c] != 8 && !(k3 && (cnt[c] == 1 || cnt[c] == 2))) return false;
     const int k = a.ncls++;
     a.cls_T[k] = cnt[c]; a.cls_py[k] = s == 2 ? c >> 1 : 0; a.cls_px[k] = s == 2 ? c & 1 : 0;
     int lo = 0, hi = 0, n = 0;

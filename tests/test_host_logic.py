@@ -35,6 +35,14 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
     assert code == declared, sorted(code ^ declared)
 
 
+def test_python_product_does_not_select_a_library_from_the_environment():
+    """`S2P_LIB` (a second build for A/B runs) is honoured by tools/uselib.py only; nothing under s2p_amd/ reads it."""
+    import glob
+    for f in glob.glob(os.path.join(ROOT, "s2p_amd", "**", "*.py"), recursive=True):
+        assert "S2P_LIB" not in open(f).read(), f
+    assert "S2P_LIB" in open(os.path.join(ROOT, "tools", "uselib.py")).read()
+
+
 def test_product_library_reads_no_environment():
     """Diagnostics (timing ablations, A/B switches) live only in the -DS2P_DIAG_BUILD library: the product .so does not
     even import getenv, so a stray S2P_* variable in a training job cannot change a kernel."""

@@ -2,6 +2,7 @@
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "oracle"))
+sys.path.insert(1, os.path.join(R, "tools")); import uselib  # noqa: E402  (S2P_LIB=<second build> for an A/B)
 import numpy as np, torch
 import slac_oracle as SO
 from s2p_amd.slac import Decoder, Encoder

@@ -1,6 +1,7 @@
 """Does the 256x256 generator forward depend on how the batch is split?  (InstanceNorm is per-sample: it must not.)"""
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "oracle"))
+sys.path.insert(1, os.path.join(R, "tools")); import uselib  # noqa: E402  (S2P_LIB=<second build> for an A/B)
 import torch
 import s2p_oracle as O
 from s2p_amd.options.test_options import TestOptions

@@ -4,6 +4,7 @@ any word that changes was written by a co-resident workgroup of the other kernel
     S2P_LIB=.../libs2p_hip_diag.so python tests/tools/repro_canary.py"""
 import ctypes, os, sys, io, contextlib
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R)
+sys.path.insert(1, os.path.join(R, "tools")); import uselib  # noqa: E402  (S2P_LIB=<second build> for an A/B)
 import torch
 from s2p_amd import ops, _lib
 from s2p_amd.models.networks.layers import ConvLayer

@@ -2,6 +2,7 @@
 side stream, with and without a heavy kernel running on the main stream, and compare the results bit for bit."""
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R)
+sys.path.insert(1, os.path.join(R, "tools")); import uselib  # noqa: E402  (S2P_LIB=<second build> for an A/B)
 import torch
 from s2p_amd import ops
 M, K, N = 64, 256, 6144

@@ -1,6 +1,7 @@
 """image_metrics beside the slab weight-gradient kernel: how large is the difference to the quiet result?"""
 import os, sys, io, contextlib
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R)
+sys.path.insert(1, os.path.join(R, "tools")); import uselib  # noqa: E402  (S2P_LIB=<second build> for an A/B)
 import torch
 from s2p_amd import ops, metrics
 from s2p_amd.models.networks.layers import ConvLayer

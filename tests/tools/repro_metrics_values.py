@@ -5,6 +5,7 @@
     S2P_LIB=.../libs2p_hip_diag.so python tests/tools/repro_metrics_values.py"""
 import ctypes, os, sys, io, contextlib, collections
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R)
+sys.path.insert(1, os.path.join(R, "tools")); import uselib  # noqa: E402  (S2P_LIB=<second build> for an A/B)
 import torch
 from s2p_amd import _lib, metrics
 from s2p_amd.models.networks.layers import ConvLayer

@@ -2,6 +2,7 @@
 identical G steps (clones taken on the stream the call runs on) and report which ones differ."""
 import os, sys, io, contextlib
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R)
+sys.path.insert(1, os.path.join(R, "tools")); import uselib  # noqa: E402  (S2P_LIB=<second build> for an A/B)
 import torch
 from s2p_amd import ops
 from s2p_amd.options.train_options import TrainOptions

@@ -2,6 +2,7 @@
 lists every parameter whose gradient differs between the runs (fp32 atomics somewhere on its weight-gradient path)."""
 import os, sys, io, contextlib
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R)
+sys.path.insert(1, os.path.join(R, "tools")); import uselib  # noqa: E402  (S2P_LIB=<second build> for an A/B)
 import torch
 from s2p_amd.options.train_options import TrainOptions
 from s2p_amd.trainers.pix2pix_trainer import Pix2PixTrainer

@@ -4,6 +4,7 @@ compared inside ONE process: capture A, time it, capture B, time it, alternating
     S2P_LIB=.../libs2p_hip_diag.so python tools/ab_step.py lib:0 3 0 1      (a run-time switch of the diagnostics library: s2p_diag_set(0, value))"""
 import os, sys, time, importlib
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+sys.path.insert(1, os.path.join(R, "tools")); import uselib  # noqa: E402  (S2P_LIB=<second build> for an A/B)
 import torch
 from s2p_amd.options.train_options import TrainOptions
 from s2p_amd.trainers.pix2pix_trainer import Pix2PixTrainer

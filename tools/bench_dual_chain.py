@@ -4,6 +4,7 @@ chain's HBM-bound norm tail / launch boundary hide under the other chain's MFMA 
 planes (cold, as in the real step); us per chain from a hipGraph."""
 import math, os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+sys.path.insert(1, os.path.join(R, "tools")); import uselib  # noqa: E402  (S2P_LIB=<second build> for an A/B)
 import torch
 from s2p_amd import ops
 from s2p_amd._lib import ACT_LRELU, EPI_ADD, EPI_STORE

@@ -1,6 +1,7 @@
 """ResBlk conv + MAT norm: separate launches vs the fused entry point (s2p_conv2d_fwd_mat), us per call from a hipGraph."""
 import math, os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+sys.path.insert(1, os.path.join(R, "tools")); import uselib  # noqa: E402  (S2P_LIB=<second build> for an A/B)
 import torch
 from s2p_amd import ops
 from s2p_amd._lib import ACT_LRELU, EPI_ADD, EPI_STORE

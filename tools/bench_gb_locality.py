@@ -3,6 +3,7 @@ A: one 12-group gamma/beta conv up front (product), then the chain of 11 fused c
 B: a one-group gamma/beta conv right before each fused conv, into a 29 MB buffer of its own.   us per chain, from a hipGraph."""
 import math, os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+sys.path.insert(1, os.path.join(R, "tools")); import uselib  # noqa: E402  (S2P_LIB=<second build> for an A/B)
 import torch
 from s2p_amd import ops
 from s2p_amd._lib import ACT_LRELU, ACT_NONE

@@ -1,6 +1,7 @@
 """l1_loss kernel timing at the VGG / feature-matching tap sizes (bf16)."""
 import sys, os
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+sys.path.insert(1, os.path.join(R, "tools")); import uselib  # noqa: E402  (S2P_LIB=<second build> for an A/B)
 import torch
 from s2p_amd import ops
 dev = torch.device("cuda:0")

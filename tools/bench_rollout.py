@@ -2,6 +2,7 @@
 Reports frames/s for the eager rollout (s2p_amd.rollout.rollout) in bf16 and fp32."""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+sys.path.insert(1, os.path.join(R, "tools")); import uselib  # noqa: E402  (S2P_LIB=<second build> for an A/B)
 import io, contextlib
 import torch
 from s2p_amd.options.test_options import TestOptions

@@ -3,7 +3,8 @@ train step: 12 ResBlk convs 256->256 and the 12 gamma/beta groups 128->512, bs 6
 (S2P_WGRAD_SLAB_SPLITS is only read there):
     bash s2p_amd/csrc/build.sh diag && S2P_LIB=$PWD/s2p_amd/csrc/libs2p_hip_diag.so python tools/bench_wgrad_slab.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+sys.path.insert(1, os.path.join(R, "tools")); import uselib  # noqa: E402  (S2P_LIB=<second build> for an A/B)
 import torch
 from s2p_amd import ops
 

@@ -3,6 +3,7 @@ A/B against the implicit-GEMM kernel:  S2P_LIB=s2p_amd/csrc/libs2p_hip_diag.so p
 (`ab`: every shape also with diagnostics switch 5 = padded-raster kernel off)."""
 import math, os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+sys.path.insert(1, os.path.join(R, "tools")); import uselib  # noqa: E402  (S2P_LIB=<second build> for an A/B)
 import torch
 from s2p_amd import ops
 from s2p_amd import _lib

@@ -2,6 +2,7 @@
 one GPU; the collectives stay outside the captured segments exactly as in bench.py)."""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+sys.path.insert(1, os.path.join(R, "tools")); import uselib  # noqa: E402  (S2P_LIB=<second build> for an A/B)
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
 import torch, torch.distributed as dist
 torch.cuda.set_device(0)

@@ -2,6 +2,7 @@
 Prints us per launch of the ResBlk conv (64 x 21 x 21, 256 -> 256) and of Cin = 64 / 128 variants (fixed vs per-step cost)."""
 import math, os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+sys.path.insert(1, os.path.join(R, "tools")); import uselib  # noqa: E402  (S2P_LIB=<second build> for an A/B)
 import torch
 from s2p_amd import ops
 dev = torch.device("cuda:0"); dt = torch.bfloat16

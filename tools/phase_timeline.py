@@ -4,6 +4,7 @@ and backward passes, the ResBlk chains and the optimizer steps, in an EAGER step
 within a few percent of the graph replay).  Prints start / end offsets (us) of every phase from the start of the step, median of 5."""
 import os, sys, io, contextlib, collections
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+sys.path.insert(1, os.path.join(R, "tools")); import uselib  # noqa: E402  (S2P_LIB=<second build> for an A/B)
 import torch
 from s2p_amd.options.train_options import TrainOptions
 from s2p_amd.trainers.pix2pix_trainer import Pix2PixTrainer
