@@ -528,6 +528,8 @@ def test_conv_small_map_splitk(hip_device, case):
     (64, 128, 4, 2, 2, False, 43, 43, 3),      # PatchGAN 4x4 stride 2 on an odd size: four classes of 4 taps, parity-1 planes one short
     (128, 256, 4, 2, 2, False, 21, 23, 2),     # ... H != W
     (256, 512, 4, 1, 2, False, 12, 12, 3),     # PatchGAN 4x4 stride 1, pad 2: two classes of 8 taps, dY one row / column larger than x
+    (128, 192, 4, 2, 2, False, 9, 13, 5),      # ... three co tiles x two ci slabs per class, a raster of 6 x 8 positions, ragged split
+    (64, 64, 4, 1, 2, False, 5, 9, 7),         # ... one tile per class, fewer raster blocks than the split target
 ])
 def test_conv_wgrad_split_units_deterministic(hip_device, case):
     """s2p_conv2d_wgrad_ws: the K-split units of the LDS-DMA weight-gradient kernel store partial tiles and a second
