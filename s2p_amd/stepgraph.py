@@ -23,6 +23,7 @@ import gc
 import torch
 
 _ACTIVE = None      # the StepGraph that is capturing right now (one per process)
+CAPTURE_PRIORITY = 0   # priority of the stream the step is captured on (-1: above the side streams); measured: see DESIGN.md 6c
 
 
 def fork(side, main=None):
@@ -99,7 +100,7 @@ class StepGraph:
         gc.collect()
         self._pool = torch.cuda.graph_pool_handle()
         global _ACTIVE
-        stream = torch.cuda.Stream()
+        stream = torch.cuda.Stream(priority=CAPTURE_PRIORITY)
         stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(stream):
             self._capturing = True
