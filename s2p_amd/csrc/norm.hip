@@ -282,10 +282,17 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const NormArgs a) {
 // TH = 256 is the form for the SMALL planes (PatchGAN 7x7 .. 13x13 maps, plain InstanceNorm: GB = false): 8 chunks per thread,
 // planes of <= 256 (bf16) / 128 (fp32) pixels.  A 1024-thread workgroup leaves most of its lanes without a pixel there and only
 // two workgroups fit a CU, so load, reduce and store phases hardly overlap; eight 256-thread workgroups per CU do.
-template <typename T, int CS, int TH = 1024, bool GB = true>   // CS = channels per workgroup: 64 (full 128-byte bf16 lines) or 32 (twice the workgroups)
+// MP > 0 (round 4): the LARGE-plane form for the plain InstanceNorms of the encoder / decoder (42x42 x 128, 84x84 x 64 channels): MP
+// chunks per thread, the plane of an (image, CS-channel slab) still in the registers of ONE workgroup -- 512 threads (a 256-VGPR
+// budget: at 1024 threads / 128 VGPRs the compiler spilled 50 of them), 112 VGPRs of payload at MP = 28: CS = 64 holds 1792
+// pixels, CS = 16 (two 16-byte chunks per pixel; the four slabs of an image run side by side on one XCD and share its 128-byte
+// lines in L2) 7168.  One read of x instead of the reduce + apply pair's two: 40.8 -> 36.4 us at 84x84 x 64 alone (the second
+// read was an infinity-cache hit), step -0.06 ms.  Half-width slabs at 14 chunks per thread (two workgroups per CU) were measured:
+// 42x42 16.9 vs 21.3 us, 84x84 51 vs 36 us, step +0.06 ms -- not kept.
+template <typename T, int CS, int TH = 1024, bool GB = true, int MP = 0>   // CS = channels per workgroup: 64 (full 128-byte bf16 lines), 32 or 16
 __global__ __launch_bounds__(TH) void in_fused_fwd_kernel(const NormArgs a) {
   constexpr int CE = DT<T>::CE;
-  constexpr int NCH = CS / CE, PR = TH / NCH, MAXP = TH == 1024 ? (DT<T>::CE == 8 ? 512 : 256) / PR : 8;   // TH 1024: planes of <= 512 (bf16) / 256 (fp32) pixels; TH 512 the same with 8 chunks per thread
+  constexpr int NCH = CS / CE, PR = TH / NCH, MAXP = MP ? MP : (TH == 1024 ? (DT<T>::CE == 8 ? 512 : 256) / PR : 8);   // TH 1024: planes of <= 512 (bf16) / 256 (fp32) pixels; TH 512 the same with 8 chunks per thread
   constexpr int RPW = 64 / NCH, NW = TH / 64, MG = GB ? MAXP : 1;
   __shared__ float red[NW][CS];
   __shared__ float cst[4][CS];
@@ -340,17 +347,30 @@ __global__ __launch_bounds__(TH) void in_fused_fwd_kernel(const NormArgs a) {
     for (int k = 0; k < MAXP; ++k) acc[e] += xv[k].get(e);            // missing pixels were loaded as zeros
   }
   plane_sum(acc, 0);
+  // large-plane form: the payload must stay PACKED between the passes (the compiler would otherwise keep all MAXP * CE unpacked
+  // floats of a pass alive for the next one: 224 VGPRs, 40 of them spilled)
+  auto keep_packed = [&]() {
+    if constexpr (MP > 0) {
 #pragma unroll
-  for (int e = 0; e < CE; ++e) {
-    mean[e] = cst[0][cc * CE + e] * inv;
-    acc[e] = 0.f;
+      for (int k = 0; k < MAXP; ++k) asm volatile("" : "+v"(xv[k].raw));
+    }
+  };
+  keep_packed();
 #pragma unroll
-    for (int k = 0; k < MAXP; ++k) {
+  for (int e = 0; e < CE; ++e) mean[e] = cst[0][cc * CE + e] * inv;
+#pragma unroll
+  for (int e = 0; e < CE; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) {
+    const bool in = pr + k * PR < a.HW;
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
       const float d = xv[k].get(e) - mean[e];
-      acc[e] += (pr + k * PR < a.HW) ? d * d : 0.f;
+      acc[e] += in ? d * d : 0.f;
     }
   }
   plane_sum(acc, 1);
+  keep_packed();
   if (tid < CS) {
     const int c = slab * CS + tid;
     if (c < a.C) {
@@ -640,6 +660,19 @@ extern "C" int s2p_in_norm_fwd(int dtype, const void* x, int N, int HW, int C, i
   if (!x || !y || !stats || N <= 0 || HW <= 0) S2P_FAIL(-1, "s2p_in_norm_fwd: null pointer / empty problem");
   const int maxhw = dtype == S2P_F32 ? 256 : 512;
   const bool simple_act = act == S2P_ACT_NONE || act == S2P_ACT_RELU || act == S2P_ACT_LRELU;   // tanh / swish: two-kernel path
+  if (dtype == S2P_BF16 && HW > maxhw && simple_act && !gb_img && S2P_DIAG_SWITCH(9) != 1 && !s2p_env_set("S2P_NO_FUSED_NORM")) {
+    // large planes, plain InstanceNorm: the register-resident form (see in_fused_fwd_kernel, MP)
+    const int cs = (HW <= 28 * 64 && C % 64 == 0) ? 64 : ((HW <= 28 * 256 && C % 16 == 0) ? 16 : 0);
+    if (cs && N * (C / cs) >= 64) {        // (a handful of workgroups: the two-kernel path spreads over more CUs)
+      NormArgs a{}; a.x = x; a.stats = stats; a.gbst = gb_st; a.y = y;
+      a.N = N; a.HW = HW; a.C = C; a.x_pitch = pitch; a.gbst_pitch = gb_st_pitch; a.y_pitch = y_pitch; a.act = act; a.slope = slope; a.eps = eps;
+      const dim3 lg(N, C / cs);
+      if (cs == 64) hipLaunchKernelGGL((in_fused_fwd_kernel<__bf16, 64, 512, false, 28>), lg, dim3(512), 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL((in_fused_fwd_kernel<__bf16, 16, 512, false, 28>), lg, dim3(512), 0, (hipStream_t)stream, a);
+      S2P_CHECK_LAUNCH("in_fused_fwd_kernel (large planes)");
+      return 0;
+    }
+  }
   if (HW > maxhw || !simple_act || s2p_env_set("S2P_NO_FUSED_NORM")) {
     rc = s2p_in_stats(dtype, x, N, HW, C, pitch, eps, stats, stream); if (rc) return rc;
     return s2p_in_apply_fwd(dtype, x, N, HW, C, pitch, stats, gb_img, gb_pitch, gb_st, gb_st_pitch, act, slope, eps, y, y_pitch, stream);

@@ -250,10 +250,13 @@ def test_instance_norm_mat(hip_device, dtype, modulated):
 @pytest.mark.parametrize("dtype,shape", [(torch.bfloat16, (5, 256, 7, 7)), (torch.bfloat16, (3, 512, 8, 8)), (torch.bfloat16, (4, 256, 12, 12)),
                                          (torch.bfloat16, (3, 512, 13, 13)), (torch.bfloat16, (2, 72, 16, 16)), (torch.bfloat16, (2, 64, 16, 17)),
                                          (torch.bfloat16, (3, 128, 22, 22)), (torch.bfloat16, (2, 64, 22, 23)),
+                                         (torch.bfloat16, (16, 256, 42, 42)), (torch.bfloat16, (16, 64, 84, 84)),     # large planes, register-resident forward:
+                                         (torch.bfloat16, (33, 128, 41, 43)), (torch.bfloat16, (20, 64, 60, 70)),     # 64- / 16-channel slabs, ragged sizes
                                          (torch.float32, (3, 132, 8, 16)), (torch.float32, (2, 64, 11, 12)), (torch.float32, (2, 68, 16, 16))])
 def test_instance_norm_small_planes(hip_device, dtype, shape):
     """The PatchGAN maps (7x7 .. 13x13, plain InstanceNorm + LeakyReLU): planes of <= 256 (bf16) / 128 (fp32) pixels take the
-    256-thread form of the fused forward / backward kernels, up to twice that the 512-thread form, 22x23 the 1024-thread form.  Against
+    256-thread form of the fused forward / backward kernels, up to twice that the 512-thread form, 22x23 the 1024-thread form; the
+    encoder / decoder planes (42x42 x 128, 84x84 x 64 channels) the large-plane form of the forward (28 chunks per thread).  Against
     float64, and against the two-kernel path (statistics + apply) on the same inputs."""
     dev = hip_device
     g = torch.Generator().manual_seed(23)
