@@ -52,6 +52,30 @@ def test_product_library_reads_no_environment():
     assert "getenv" not in out
 
 
+def test_weight_gradient_workspace_plans_run_without_a_gpu():
+    """Size queries are host logic (no launch): the K-split / tile-class plan of the padded-raster 4x4 weight gradient
+    (csrc/wgrad_slabg.hip) for the PatchGAN layers of the train step -- classes x tiles x splits partial tiles of 64 x T x 64
+    floats + the bias partials -- and the queries' refusal of what no kernel takes."""
+    import ctypes
+    from s2p_amd import ops
+    L = _lib.lib()
+
+    def need(cin, cout, k, s, p, N, H, W):
+        geom = ops.ConvGeom(cin, cout, k, s, p)
+        d = geom.desc(torch.bfloat16, N, H, W, cin, cin, cout)
+        return int(L.s2p_conv2d_wgrad_workspace(ctypes.byref(d), cin, cout))
+
+    # 256 -> 512, 4x4 stride 1 pad 2 on 12x12 (N 128): 2 classes (8 taps) x 32 tiles x 8 splits; at least that many partial tiles
+    assert need(256, 512, 4, 1, 2, 128, 12, 12) >= (2 * 32 * 8 * 64 * 8 * 64 + 8 * 8 * 64) * 4
+    # 64 -> 128, 4x4 stride 2 on 43x43: 4 parity classes (4 taps) x 2 tiles x 63 splits (1 058 raster blocks of 64 positions in
+    # runs of 17) of 64 x 4 x 64 floats + 2 x 63 x 64 bias partials: exactly this many bytes
+    assert need(64, 128, 4, 2, 2, 128, 43, 43) == (4 * 2 * 63 * 64 * 4 * 64 + 2 * 63 * 64) * 4
+    # a layer neither weight-gradient kernel family splits deterministically asks for nothing
+    assert need(64, 128, 3, 2, 1, 4, 20, 20) > 0            # implicit GEMM: K-split partial tiles
+    d = ops.ConvGeom(64, 128, 4, 2, 2).desc(torch.float32, 2, 9, 9, 64, 64, 128)
+    assert int(L.s2p_conv2d_wgrad_workspace(ctypes.byref(d), 64, 128)) == 0     # fp32 path: atomics, no scratch
+
+
 def test_struct_layouts_match_header():
     import ctypes
     assert ctypes.sizeof(_lib.ConvDesc) == 20 * 4
