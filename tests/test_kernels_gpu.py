@@ -1017,6 +1017,9 @@ def test_plane_pair_kernel_production_groups(hip_device):
     ops.conv_fwd(ggm, xd, wfg, bg.to(dev), ci, y_pitch=co, act=ACT_NONE, out=y5[0])
     dy5 = torch.randn(G, N, H, W, co, generator=g).to(dtype).to(dev)
     dx = ops.conv_dgrad(ggm, dy5[0], wbg, (N, H, W, G * ci), ci)
+    # ... and with the producer-activation-gradient epilogue the generator's backward uses (aux = the ReLU'd conditioning features):
+    # the persistent form applies it from registers, 8 bytes per lane
+    dx2 = ops.conv_dgrad(ggm, dy5[0], wbg, (N, H, W, G * ci), ci, aux=xd, epi=EPI_MUL_ACTGRAD, aux_act=ACT_RELU)
     torch.cuda.synchronize()
     assert not bool(torch.isnan(y5.float()).any())
     for i in gpick:
@@ -1026,6 +1029,8 @@ def test_plane_pair_kernel_production_groups(hip_device):
         dyi = dy5[i].float().cpu().permute(0, 3, 1, 2)[pick].double()
         refd = F.conv_transpose2d(dyi, wi, padding=1)
         assert rel_err(nchw(dx, G * ci)[pick, i * ci:(i + 1) * ci], refd) < TOL[dtype], i
+        xi = xg[pick, i * ci:(i + 1) * ci].double()
+        assert rel_err(nchw(dx2, G * ci)[pick, i * ci:(i + 1) * ci], refd * (xi > 0)) < TOL[dtype], i
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
