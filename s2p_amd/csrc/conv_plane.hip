@@ -29,8 +29,10 @@ __device__ __forceinline__ void pl_static_for(F&& f) {
   if constexpr (B < E) { f(std::integral_constant<int, B>{}); pl_static_for<B + 1, E>(f); }
 }
 
-// DMA with the uniform part of the source offset in an SGPR (soffset); the range check uses voffset only, so an invalid
-// lane (voffset >= num_records) still returns zeros.
+// DMA with the uniform part of the source offset in an SGPR (soffset).  An invalid lane carries voffset = 0x80000000 and returns
+// zeros whatever the scalar part is.  The scalar part COUNTS in the range check on gfx950 (measured in round 4: a group offset
+// beyond num_records in soffset zero-filled valid lanes), so num_records must cover base + voffset + soffset of every valid lane:
+// here the scalar part is a channel offset inside a pixel row / a tap offset inside a weight row, both inside the records.
 __device__ __forceinline__ void pl_dma16(i32x4 rsrc, unsigned lds_dst, int voffset, int soffset) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
                :: "v"(voffset), "s"(rsrc), "s"(lds_dst), "s"(soffset) : "memory", "m0");
