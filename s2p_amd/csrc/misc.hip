@@ -888,7 +888,8 @@ extern "C" __attribute__((visibility("default"))) int s2p_diag_vgpr_canary(int b
 // 3 = no 4-channel-pitch kernel for the 7x7 thin convs (stem forward, output-conv dgrad), 4 = no row-band form of the generalised plane kernel,
 // 5 = no padded-raster weight gradient of the 4x4 layers (wgrad_slabg.hip), 6 = that kernel also for the 3x3 stride-2 layers,
 // 8 = no 192-pixel row bands for the short-K layers (VGG conv1_2 / conv2_x take the 448-pixel bands),
-// 9 = no register-resident InstanceNorm forward for the large planes (reduce + apply instead)
+// 9 = no register-resident InstanceNorm forward for the large planes (reduce + apply instead),
+// 13 = the VALU / shuffle form of the PatchGAN logit-head forward instead of the MFMA one
 int s2p_diag_switch[16] = {0};
 extern "C" __attribute__((visibility("default"))) int s2p_diag_set(int key, int value) {
   if (key < 0 || key >= 16) return -1;

@@ -243,6 +243,53 @@ __global__ __launch_bounds__(1024) void head_fwd_kernel(const HeadFwdArgs a) {
   }
 }
 
+// The same forward on the matrix cores (round 4).  P[pixel][tap] = sum_ci x[pixel][ci] * w[tap][ci] is a 169 x 16 x 512 GEMM per
+// image: a wave owns 16 consecutive input pixels, its A fragments (16 pixels x 32 channels) are plain 16-byte global loads in the
+// MFMA's own operand layout (lane (q, l15): pixel l15, channels 8 q .. 8 q + 7), the B fragments (32 channels x 16 taps) come
+// straight from the 16-KB weight array -- all 2 x 16 loads of a wave are in flight before the first of its 16
+// v_mfma_f32_16x16x32_bf16.  The per-tap products go to an LDS table [pixel][tap]; after one barrier each OUTPUT pixel adds its
+// <= 16 entries (oy = iy + pad - ky, ox = ix + pad - kx) in tap order: reproducible, no shuffles.  18 -> 6 us at 64 x 13 x 13.
+__global__ __launch_bounds__(1024) void head_fwd_mfma_kernel(const HeadFwdArgs a) {
+  constexpr int KS = 4, T = 16, NS = 16;                    // 4x4 taps, 16 K steps of 32 channels (Cin = 512)
+  __shared__ float P[256][T + 1];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int tile = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, l15 = lane & 15;
+  const int n = blockIdx.x, HW = a.H * a.W;
+  int p = tile * 16 + l15;
+  const bool pok = p < HW;
+  if (!pok) p = HW - 1;
+  const __bf16* xp = a.x + ((size_t)n * HW + p) * a.x_pitch + 8 * q;
+  const __bf16* wp = a.w + (size_t)l15 * 512 + 8 * q;
+  bf16x8 xa[NS], wb[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) xa[s] = *(const bf16x8*)(xp + 32 * s);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) wb[s] = *(const bf16x8*)(wp + 32 * s);
+  typedef __attribute__((ext_vector_type(4))) float f32x4h;
+  f32x4h acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < NS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[s], wb[s], acc, 0, 0, 0);
+  // D[row = 4 q + e][col = l15]: pixel tile * 16 + 4 q + e, tap l15
+#pragma unroll
+  for (int e = 0; e < 4; ++e) P[tile * 16 + 4 * q + e][l15] = acc[e];
+  __syncthreads();
+  for (int o = tid; o < a.Ho * a.Wo; o += blockDim.x) {
+    const int oy = o / a.Wo, ox = o - oy * a.Wo;
+    float sum = a.bias ? a.bias[0] : 0.f;
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+        const int iy = oy - a.pad + ky, ix = ox - a.pad + kx;
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) sum += P[iy * a.W + ix][ky * KS + kx];
+      }
+    Chunk<__bf16> c; c.raw = (u32x4){0u, 0u, 0u, 0u};
+    c.set(0, act_fwd(sum, a.act, a.slope));
+    *(u32x4*)(a.y + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.y_pitch) = c.raw;
+  }
+}
+
 bool s2p_head_fwd_applicable(const s2p_conv_desc* d) {
   return d->dtype == S2P_BF16 && d->groups == 1 && !d->transposed && !d->reflect && d->stride == 1 && d->Cout == 1 &&
          d->KH == 4 && d->KW == 4 && d->Cin == 512 && d->x_pitch % 8 == 0 && d->y_pitch == 8 && d->H <= 16 && d->Wo <= 24 &&
@@ -255,6 +302,11 @@ int s2p_head_fwd(const s2p_conv_desc* d, const void* x, const void* w, const flo
   a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = bias; a.y = (__bf16*)y;
   a.N = d->N; a.H = d->H; a.W = d->W; a.x_pitch = d->x_pitch; a.Ho = d->Ho; a.Wo = d->Wo; a.y_pitch = d->y_pitch;
   a.pad = d->pad; a.act = act; a.slope = slope;
+  if (!S2P_DIAG_SWITCH(13) && d->H * d->W <= 256) {
+    hipLaunchKernelGGL(head_fwd_mfma_kernel, dim3(d->N), dim3(64 * cdiv(d->H * d->W, 16)), 0, st, a);
+    S2P_CHECK_LAUNCH("head_fwd_mfma_kernel");
+    return 0;
+  }
   hipLaunchKernelGGL(head_fwd_kernel, dim3(d->N), dim3(64 * d->H), 0, st, a);
   S2P_CHECK_LAUNCH("head_fwd_kernel");
   return 0;

@@ -57,6 +57,7 @@ CONV_CASES = [
     (64, 128, 4, 1, 2, False, False, 6, 6, 2),     # PatchGAN stride-1 layer
     (128, 1, 4, 1, 2, False, False, 7, 7, 2),      # PatchGAN head
     (512, 1, 4, 1, 2, False, False, 6, 5, 3),      # PatchGAN head at the real width (x-stationary Cout=1 wgrad, 64 chunks)
+    (512, 1, 4, 1, 2, False, False, 13, 13, 4),    # ... at the real map size: the MFMA forward's 11 pixel tiles per image (the last one partial)
     (40, 72, 1, 1, 0, False, False, 1, 1, 64),     # linear layer as 1x1 conv (non power-of-two channels)
     (128, 192, 3, 1, 1, False, False, 21, 21, 3),  # halo-resident fast path: 2 channel slabs, tiles spanning rows and images
     (64, 160, 5, 1, 2, False, False, 17, 23, 2),   # halo-resident path, 5x5 taps, ragged Cout tile
