@@ -556,8 +556,22 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const T* dy, long long
   float q[CE];
 #pragma unroll
   for (int e = 0; e < CE; ++e) q[e] = 0.f;
-  if (cc < nch)
-    for (long long p = p0 + pr; p < p1; p += PR) {
+  if (cc < nch) {
+    long long p = p0 + pr;
+    if (c0 + CE <= C) {
+      // four rows in flight per thread (one dependent load per pass left the kernel latency-bound: 2.2 TB/s on the 87-MB gradient
+      // of the conditioning conv); the sums are added in row order
+      for (; p + 3 * PR < p1; p += 4 * PR) {
+        Chunk<T> v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u].raw = *(const u32x4*)(dy + (size_t)(p + u * PR) * pitch + c0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < CE; ++e) q[e] += v[u].get(e);
+      }
+    }
+    for (; p < p1; p += PR) {
       if (c0 + CE <= C) {
         Chunk<T> v; v.raw = *(const u32x4*)(dy + (size_t)p * pitch + c0);
 #pragma unroll
@@ -566,6 +580,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const T* dy, long long
         for (int e = 0; e < CE; ++e) if (c0 + e < C) q[e] += to_f32(dy[(size_t)p * pitch + c0 + e]);
       }
     }
+  }
 #pragma unroll
   for (int e = 0; e < CE; ++e) red[tid][e] = q[e];
   __syncthreads();
@@ -786,7 +801,11 @@ extern "C" int s2p_in_norm_bwd_res(int dtype, const void* da, int da_pitch, cons
 }
 
 static void channel_sum_geom(int64_t pixels, int C, int& nb, int& rows) {
-  nb = (int)((pixels + 2047) / 2048); if (nb > 256) nb = 256; if (nb < 1) nb = 1;
+  // pixel blocks: ~1 500 workgroups over (channel slabs x blocks), at least 128 pixels each, at most 256 blocks
+  const int slabs = (C + 63) / 64;
+  nb = (1536 + slabs - 1) / slabs;
+  if ((int64_t)nb * 128 > pixels) nb = (int)(pixels / 128);
+  if (nb > 256) nb = 256; if (nb < 1) nb = 1;
   rows = (int)((pixels + nb - 1) / nb);
   nb = (int)((pixels + rows - 1) / rows);
 }
