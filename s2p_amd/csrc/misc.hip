@@ -889,7 +889,8 @@ extern "C" __attribute__((visibility("default"))) int s2p_diag_vgpr_canary(int b
 // 5 = no padded-raster weight gradient of the 4x4 layers (wgrad_slabg.hip), 6 = that kernel also for the 3x3 stride-2 layers,
 // 8 = no 192-pixel row bands for the short-K layers (VGG conv1_2 / conv2_x take the 448-pixel bands),
 // 9 = no register-resident InstanceNorm forward for the large planes (reduce + apply instead),
-// 13 = the VALU / shuffle form of the PatchGAN logit-head forward instead of the MFMA one
+// 13 = the VALU / shuffle form of the PatchGAN logit-head forward instead of the MFMA one,
+// 14 = the stem's weight gradient on the implicit GEMM instead of the row-streaming kernel with exchanged operands
 int s2p_diag_switch[16] = {0};
 extern "C" __attribute__((visibility("default"))) int s2p_diag_set(int key, int value) {
   if (key < 0 || key >= 16) return -1;

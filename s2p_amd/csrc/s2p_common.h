@@ -144,6 +144,10 @@ int s2p_thin_fwd(const s2p_conv_desc* d, const void* x, const void* w, const flo
                  hipStream_t st);
 int s2p_thin_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, int cin_real, void* ws, size_t ws_bytes, hipStream_t st);
 size_t s2p_thin_wgrad_ws_bytes(const s2p_conv_desc* d, int cin_real);
+// the stem's weight gradient (thin input 3 -> 64, 7x7) on the row-streaming kernel with exchanged operands (thin_conv.hip)
+bool s2p_stem_wgrad_applicable(const s2p_conv_desc* d, int cin_real, int cout_real);
+size_t s2p_stem_wgrad_ws_bytes(const s2p_conv_desc* d, int cin_real);
+int s2p_stem_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, float* db, int cin_real, void* ws, size_t ws_bytes, hipStream_t st);
 size_t s2p_channel_sum_ws_bytes(int64_t pixels, int C);
 int s2p_channel_sum_det(int dtype, const void* dy, int64_t pixels, int C, int pitch, float* db, void* ws, size_t ws_bytes, void* stream);
 // row-streaming thin-Cout kernels (thin_rows.hip)

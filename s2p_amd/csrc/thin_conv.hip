@@ -444,7 +444,7 @@ __global__ __launch_bounds__(512) void thin_tiled_wgrad_kernel(const TileArgs a)
 // ---- 7x7 stride-1 pad-3 weight gradient with Cin = 64 and Cout <= 4 (the generator's output conv), row-streaming form (round 4) ------
 // The tiled kernel above re-reads x 2.4 times (16x8 tiles with a 6-pixel halo), loads each halo synchronously and spends an MFMA
 // per (tap, 16 channels) with 3 of its 16 rows used: 125 us, alone on the chip at the start of the generator's backward.  Here
-//   * a workgroup owns a BAND of 21 output rows of one image over the full width and streams the input rows once through an
+//   * a workgroup owns a BAND of 21-23 output rows of one image over the full width and streams the input rows once through an
 //     8-row LDS ring (1.29x instead of 2.4x; the next row's global loads are in flight while the current one is computed);
 //   * the MFMA's thin side carries (kx, co) -- 21 of 32 rows used instead of 3 of 16: for a fixed ky,
 //         dW[co][ky][kx][ci] = sum_{p'} dY[row][p' - kx][co] * X[row + ky][p'][ci]
@@ -452,10 +452,20 @@ __global__ __launch_bounds__(512) void thin_tiled_wgrad_kernel(const TileArgs a)
 //     fragment is one aligned 16-byte read) and B[k = p'][ci] is the halo row through ds_read_b64_tr_b16, one k-chunk = 32 columns;
 //   * wave (m tile, 16-channel group) keeps the accumulators of all seven ky: an input row is read from LDS once and used by up
 //     to seven output rows.
-constexpr int R7_XC = 96, R7_XS = 144, R7_BAND = 21, R7_MR = 24;
+constexpr int R7_XC = 96, R7_XS = 144, R7_MR = 24;
+// rows per band: the fewest bands of at most 23 rows, equal in length (84 rows: 4 x 21; the stem's padded 90 rows: 4 x 23 -- 64 images x 4
+// bands are ONE round of the 256 CUs; 5 bands of 21 were two rounds: 96 us against 52)
+static inline int r7_nbands(int H) { return (H + 22) / 23; }
+static inline int r7_band(int H) { const int nb = r7_nbands(H); return (H + nb - 1) / nb; }
 struct Rows7Args {
   const __bf16* x; const __bf16* dy; float* dw; float* part;
   int N, H, W, x_pitch, y_pitch, Cout, cin_real, reflect, nbands;
+  // SWAPPED use (the stem 3 -> 64: thin INPUT, wide OUTPUT gradient): `dy` is the reflect- / zero-padded input on the (H, W) grid =
+  // image + 6, `x` is the 64-channel output gradient of (Hw, Ww) = the image, sitting at offset woff = 3 inside that grid (zeros
+  // around it); the result is the stem's gradient with both taps flipped and the channel roles exchanged (swap != 0):
+  //   G[c3][ky][kx][c64] = sum_p thin[p][c3] * wide[p + (ky - 3, kx - 3)][c64] = dW_stem[c64][6 - ky][6 - kx][c3]
+  int Hw, Ww, woff, swap;
+  int band;                                              // rows per band (r7_band)
 };
 
 __global__ __launch_bounds__(512) void thin_rows7_wgrad_kernel(const Rows7Args a) {
@@ -466,8 +476,8 @@ __global__ __launch_bounds__(512) void thin_rows7_wgrad_kernel(const Rows7Args a
   const int q = (lane >> 2) & 3, p = lane & 3;           // transposed-read lane roles inside the 16-lane group
   const int cg = wave & 3, mt = wave >> 2;
   const int n = blockIdx.x / a.nbands, band = blockIdx.x - n * a.nbands;
-  const int r0 = band * R7_BAND;
-  const int nrows = a.H - r0 < R7_BAND ? a.H - r0 : R7_BAND;
+  const int r0 = band * a.band;
+  const int nrows = a.H - r0 < a.band ? a.H - r0 : a.band;
   const int M = 7 * a.Cout;
   for (int i = tid; i < 8 * R7_XC * R7_XS / 16; i += 512) ((u32x4*)xring)[i] = (u32x4){0u, 0u, 0u, 0u};
   for (int i = tid; i < 8 * R7_MR * R7_XC * 2 / 16; i += 512) ((u32x4*)dyc)[i] = (u32x4){0u, 0u, 0u, 0u};
@@ -477,20 +487,20 @@ __global__ __launch_bounds__(512) void thin_rows7_wgrad_kernel(const Rows7Args a
   const int ncols = a.W + 6;                             // halo columns: image columns -3 .. W + 2
   u32x4 xv[2], dv;
   auto load_row = [&](int h) {                           // halo row h of x and output row h of dY -> registers
-    int iy = r0 - 3 + h;
+    int iy = r0 - 3 + h - a.woff;                          // row of the wide tensor (its own grid: Hw x Ww at offset woff)
     bool rok = true;
-    if (a.reflect) { iy = iy < 0 ? -iy : (iy >= a.H ? 2 * a.H - 2 - iy : iy); iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy); }
-    else rok = iy >= 0 && iy < a.H;
+    if (a.reflect) { iy = iy < 0 ? -iy : (iy >= a.Hw ? 2 * a.Hw - 2 - iy : iy); iy = iy < 0 ? 0 : (iy >= a.Hw ? a.Hw - 1 : iy); }
+    else rok = iy >= 0 && iy < a.Hw;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int idx = tid + 512 * i, col = idx >> 3, ch = idx & 7;
       xv[i] = (u32x4){0u, 0u, 0u, 0u};
       if (col < ncols) {
-        int ix = col - 3;
+        int ix = col - 3 - a.woff;
         bool ok = rok;
-        if (a.reflect) { ix = ix < 0 ? -ix : (ix >= a.W ? 2 * a.W - 2 - ix : ix); ix = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix); }
-        else ok = ok && ix >= 0 && ix < a.W;
-        if (ok) xv[i] = *(const u32x4*)(a.x + (((size_t)n * a.H + iy) * a.W + ix) * a.x_pitch + ch * 8);
+        if (a.reflect) { ix = ix < 0 ? -ix : (ix >= a.Ww ? 2 * a.Ww - 2 - ix : ix); ix = ix < 0 ? 0 : (ix >= a.Ww ? a.Ww - 1 : ix); }
+        else ok = ok && ix >= 0 && ix < a.Ww;
+        if (ok) xv[i] = *(const u32x4*)(a.x + (((size_t)n * a.Hw + iy) * a.Ww + ix) * a.x_pitch + ch * 8);
       }
     }
     dv = (u32x4){0u, 0u, 0u, 0u};
@@ -558,7 +568,8 @@ __global__ __launch_bounds__(512) void thin_rows7_wgrad_kernel(const Rows7Args a
         const int mm = 16 * mt + 4 * kg + e;
         if (mm < M) {
           const int kx = mm / a.Cout, co = mm - kx * a.Cout;
-          const size_t o = ((size_t)co * 49 + ky * 7 + kx) * a.cin_real + ci;
+          const size_t o = a.swap ? ((size_t)ci * 49 + (6 - ky) * 7 + (6 - kx)) * a.Cout + co          // dW_stem[c64][6 - ky][6 - kx][c3]
+                                  : ((size_t)co * 49 + ky * 7 + kx) * a.cin_real + ci;
           if (a.part) a.part[(size_t)blockIdx.x * ((size_t)a.Cout * 49 * a.cin_real) + o] = acc[ky][e];
           else atomicAdd(a.dw + o, acc[ky][e]);
         }
@@ -571,7 +582,7 @@ static bool rows7_applicable(const s2p_conv_desc* d) {
          d->pad == 3 && d->Cin == 64 && d->x_pitch == 64 && d->y_pitch == 8 && d->Ho == d->H && d->Wo == d->W && d->W + 6 <= R7_XC &&
          d->W <= 512 && d->H >= 7;
 }
-static int rows7_blocks(const s2p_conv_desc* d) { return d->N * cdiv(d->H, R7_BAND); }
+static int rows7_blocks(const s2p_conv_desc* d) { return d->N * r7_nbands(d->H); }
 
 static bool tiled_applicable(const s2p_conv_desc* d) {
   if (!(d->dtype == S2P_BF16 && d->groups == 1 && !d->transposed && d->Cout <= 4 && d->stride == 1 && d->KH == d->KW &&
@@ -623,7 +634,8 @@ int s2p_thin_tiled_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, 
   const size_t need = s2p_thin_wgrad_ws_bytes(d, cin_real);
   a.part = (ws && need > 0 && ws_bytes >= need) ? (float*)ws : nullptr;
   if (rows7_applicable(d) && !S2P_DIAG_SWITCH(1)) {
-    Rows7Args r{a.x, a.dy, dw, a.part, d->N, d->H, d->W, d->x_pitch, d->y_pitch, d->Cout, cin_real, d->reflect, cdiv(d->H, R7_BAND)};
+    Rows7Args r{a.x, a.dy, dw, a.part, d->N, d->H, d->W, d->x_pitch, d->y_pitch, d->Cout, cin_real, d->reflect, r7_nbands(d->H),
+                d->H, d->W, 0, 0, r7_band(d->H)};
     const int blocks = rows7_blocks(d);
     hipLaunchKernelGGL(thin_rows7_wgrad_kernel, dim3(blocks), dim3(512), 0, st, r);
     S2P_CHECK_LAUNCH("thin_rows7_wgrad_kernel");
@@ -649,5 +661,70 @@ int s2p_thin_tiled_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, 
     s2p_partial_reduce(a.part, blocks, n, n, dw, st);          // dw += the workgroups' partial tiles, in a fixed order
     S2P_CHECK_LAUNCH("s2p_partial_reduce_kernel(thin tiled wgrad)");
   }
+  return 0;
+}
+
+// ---- the STEM's weight gradient (3 -> 64, 7x7, stride 1, pad 3: thin INPUT) on the row-streaming kernel with the operands exchanged ----
+// dW[co][ky][kx][ci] = sum_p dY[p][co] * Xpad[p + (ky, kx)][ci]  =  sum_P Xpad[P][ci] * dY[P - (ky, kx)][co]   (P on the padded grid):
+// the same sum with the THIN tensor (the padded image, 3 channels) at the centre position and the WIDE one (dY, 64 channels) read at
+// the negated tap -- thin_rows7_wgrad_kernel's form with flipped taps (Rows7Args::swap).  The implicit GEMM ran this layer with a
+// half-empty A tile, 8-channel pads for 3 channels and 128 K splits: 101 us + reduce at 78 TFLOP/s, the last conv launch of the generator's
+// backward.  A small kernel writes the padded (reflect / zero) 8-channel-pitch copy of the image first.
+struct Pad8Args { const __bf16* x; __bf16* y; int N, H, W, x_pitch, pad, reflect; };
+__global__ __launch_bounds__(256) void pad8_kernel(const Pad8Args a) {
+  const int Hp = a.H + 2 * a.pad, Wp = a.W + 2 * a.pad;
+  const long long total = (long long)a.N * Hp * Wp;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int n = (int)(i / ((long long)Hp * Wp));
+    const int r = (int)(i - (long long)n * Hp * Wp);
+    int iy = r / Wp - a.pad, ix = r % Wp - a.pad;
+    bool ok = true;
+    if (a.reflect) {
+      iy = iy < 0 ? -iy : (iy >= a.H ? 2 * a.H - 2 - iy : iy); ix = ix < 0 ? -ix : (ix >= a.W ? 2 * a.W - 2 - ix : ix);
+    } else ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (ok) v = *(const u32x4*)(a.x + (((size_t)n * a.H + iy) * a.W + ix) * a.x_pitch);
+    *(u32x4*)(a.y + (size_t)i * 8) = v;
+  }
+}
+
+bool s2p_stem_wgrad_applicable(const s2p_conv_desc* d, int cin_real, int cout_real) {
+  return d->dtype == S2P_BF16 && d->groups == 1 && !d->transposed && d->KH == 7 && d->KW == 7 && d->stride == 1 && d->pad == 3 &&
+         d->Cin == 8 && d->x_pitch == 8 && cin_real >= 1 && cin_real <= 4 && d->Cout == 64 && cout_real == 64 && d->y_pitch == 64 &&
+         d->Ho == d->H && d->Wo == d->W && d->W + 12 <= R7_XC && d->H >= 7 && (!d->reflect || (d->H >= 4 && d->W >= 4)) &&
+         !S2P_DIAG_SWITCH(14);
+}
+static inline size_t stem_align(size_t b) { return (b + 255) / 256 * 256; }
+size_t s2p_stem_wgrad_ws_bytes(const s2p_conv_desc* d, int cin_real) {
+  const size_t padded = stem_align((size_t)d->N * (d->H + 6) * (d->W + 6) * 8 * sizeof(__bf16));
+  const size_t parts = stem_align((size_t)d->N * r7_nbands(d->H + 6) * cin_real * 49 * 64 * sizeof(float));
+  return padded + parts + s2p_channel_sum_ws_bytes((int64_t)d->N * d->H * d->W, 64);      // (+ the bias gradient's partial sums)
+}
+int s2p_stem_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float* dw, float* db, int cin_real, void* ws, size_t ws_bytes,
+                   hipStream_t st) {
+  if (!ws || ws_bytes < s2p_stem_wgrad_ws_bytes(d, cin_real)) S2P_FAIL(-1, "s2p_stem_wgrad: workspace of %zu bytes needed", s2p_stem_wgrad_ws_bytes(d, cin_real));
+  const int Hp = d->H + 6, Wp = d->W + 6;
+  __bf16* xpad = (__bf16*)ws;
+  const size_t padded = stem_align((size_t)d->N * Hp * Wp * 8 * sizeof(__bf16));
+  const size_t parts = stem_align((size_t)d->N * r7_nbands(Hp) * cin_real * 49 * 64 * sizeof(float));
+  float* part = (float*)((char*)ws + padded);
+  if (db) {
+    int rc = s2p_channel_sum_det(d->dtype, dy, (int64_t)d->N * d->H * d->W, 64, d->y_pitch, db, (char*)ws + padded + parts,
+                                 s2p_channel_sum_ws_bytes((int64_t)d->N * d->H * d->W, 64), st);
+    if (rc) return rc;
+  }
+  Pad8Args p{(const __bf16*)x, xpad, d->N, d->H, d->W, d->x_pitch, 3, d->reflect};
+  const long long total = (long long)d->N * Hp * Wp;
+  int pb = (int)((total + 255) / 256); if (pb > 4096) pb = 4096;
+  hipLaunchKernelGGL(pad8_kernel, dim3(pb), dim3(256), 0, st, p);
+  S2P_CHECK_LAUNCH("pad8_kernel");
+  const int nbands = r7_nbands(Hp), blocks = d->N * nbands;
+  // wide := dY (64 channels, image grid at offset 3 of the padded grid, zeros around), thin := the padded image (Cout field = its channels)
+  Rows7Args r{(const __bf16*)dy, xpad, dw, part, d->N, Hp, Wp, d->y_pitch, 8, cin_real, 64, 0, nbands, d->H, d->W, 3, 1, r7_band(Hp)};
+  hipLaunchKernelGGL(thin_rows7_wgrad_kernel, dim3(blocks), dim3(512), 0, st, r);
+  S2P_CHECK_LAUNCH("thin_rows7_wgrad_kernel(stem)");
+  const int n = cin_real * 49 * 64;
+  s2p_partial_reduce(part, blocks, n, n, dw, st);
+  S2P_CHECK_LAUNCH("s2p_partial_reduce_kernel(stem wgrad)");
   return 0;
 }

@@ -548,7 +548,8 @@ extern "C" size_t s2p_conv2d_wgrad_workspace(const s2p_conv_desc* d, int cin_rea
     return t ? ws_align(t) + wgrad_bias_ws_bytes(d, cout_real) : 0;
   }
   // strided / 4x4 layers: padded-raster slab kernel (wgrad_slabg.hip); the scratch serves either kernel
-  const size_t sg = s2p_wgrad_slabg_workspace(d, cin_real, cout_real);
+  size_t sg = s2p_wgrad_slabg_workspace(d, cin_real, cout_real);
+  if (s2p_stem_wgrad_applicable(d, cin_real, cout_real)) { const size_t t = s2p_stem_wgrad_ws_bytes(d, cin_real); if (t > sg) sg = t; }
   bool dense = true;
   WgradArgs a{};
   if (!wgrad_dma_plan(d, cin_real, cout_real, a, dense)) return sg;
@@ -588,6 +589,8 @@ extern "C" int s2p_conv2d_wgrad_ws(const s2p_conv_desc* d, const void* x, const 
     return s2p_thin_wgrad(d, x, dy, dw, cin_real, det ? workspace : nullptr, det ? tw : 0, (hipStream_t)stream);
   }
   hipStream_t st = (hipStream_t)stream;
+  if (workspace && s2p_stem_wgrad_applicable(d, cin_real, cout_real) && workspace_bytes >= s2p_stem_wgrad_ws_bytes(d, cin_real))
+    return s2p_stem_wgrad(d, x, dy, dw, db, cin_real, workspace, workspace_bytes, st);
   if (workspace && s2p_wgrad_slabg_supported(d, cin_real, cout_real) &&
       workspace_bytes >= s2p_wgrad_slabg_workspace(d, cin_real, cout_real))
     return s2p_wgrad_slabg(d, x, dy, dw, db, cin_real, cout_real, workspace, workspace_bytes, st);

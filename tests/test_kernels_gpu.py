@@ -70,6 +70,8 @@ CONV_CASES = [
     (3, 64, 3, 1, 1, False, False, 9, 35, 3),      # ... two waves, one short band
     (3, 200, 3, 1, 1, False, False, 21, 21, 2),    # conditioning conv 3 -> many: thin-input forward kernel, 4 channel blocks (ragged)
     (3, 64, 7, 1, 3, False, True, 84, 84, 1),      # stem at the train size: thin-input forward kernel, several tiles per wave
+    (3, 64, 7, 1, 3, False, False, 30, 40, 3),     # stem-like with zero padding: weight gradient on the row-streaming kernel with exchanged operands (2 bands of 18 rows)
+    (3, 64, 7, 1, 3, False, True, 25, 31, 2),      # ... reflect padding, one band of 31 -> two of 16 rows (the second short)
     (256, 128, 3, 1, 1, False, False, 19, 21, 8),  # plane-resident kernel (bf16): 8 half-slabs, XCD-aware (image, slab) order, H != W
     (64, 64, 3, 1, 1, False, False, 20, 17, 9),    # plane-resident kernel: one co slab, 340-px plane (last blocks padded), N % 8 != 0
     (192, 64, 3, 1, 1, False, False, 21, 21, 2),   # plane-resident kernel: odd number of 64-channel input slabs
