@@ -138,7 +138,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the export is missing
             fn.argtypes = args
             fn.restype = _RESTYPE.get(name, c_int)
-        if L.s2p_version() < 120:
+        if L.s2p_version() < 121:
             raise RuntimeError("libs2p_hip.so is older than this package")
         _lib = L
     return _lib

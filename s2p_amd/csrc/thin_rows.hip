@@ -239,8 +239,8 @@ int s2p_thin_rows_dgrad(const s2p_conv_desc* d, const void* dy, const void* w_bw
 // is TWO taps of one pixel column: the B fragment of lane (pixel, half) is the 16-byte pixel of tap 2s + half, loaded
 // straight from global memory (32 consecutive pixels of a row = 512 contiguous bytes: coalesced, and the 7 MB input stays
 // in L1 / L2 across its T re-reads) -- no LDS staging, no gather index tables.  The weights (64 output channels x K) sit
-// in LDS in fragment order.  A wave owns 32 consecutive output pixels x 64 channels; the two lane halves swap 8-byte
-// pieces at the end so that every store is a full 16-byte channel chunk.
+// in LDS in fragment order.  A wave owns 32 consecutive output pixels x 64 channels and transposes them through a private LDS strip so
+// that every store instruction writes full 128-byte rows.
 struct CinArgs {
   const __bf16* x; const __bf16* w; const float* bias; __bf16* y;
   int N, H, W, Ho, Wo, Cout, y_pitch, stride, pad, reflect, act;
@@ -248,6 +248,7 @@ struct CinArgs {
   int M, tiles, x_bytes;
 };
 
+constexpr int CIN_SRS = 144;                 // staging-strip row: 64 channels x 2 B + 16
 template <int KS>
 __global__ __launch_bounds__(256) void thin_cin_fwd_kernel(const CinArgs a) {
   constexpr int T = KS * KS, NK = (T + 1) / 2;
@@ -353,20 +354,25 @@ __global__ __launch_bounds__(256) void thin_cin_fwd_kernel(const CinArgs a) {
         const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
         pk[ct][q] = __builtin_bit_cast(u32x2, o);
       }
-    // half 0 stores the chunks q = 0, 1 (it needs the partner's 8 bytes of those), half 1 the chunks q = 2, 3
-    __bf16* yp = a.y + (size_t)m * a.y_pitch;
+    // transpose through the wave's private strip (32 pixel rows of 128 + 16 bytes) so that a store instruction writes FULL 128-byte
+    // rows -- 8 lanes per pixel, 8 pixels per instruction (16-byte pieces 32 bytes apart wrote these 58-87-MB outputs at 2.3-2.8 TB/s).
+    // DS operations of one wave execute in order: no wait between the passes.
+    {
+      char* strip = smem + 2 * NK * 1024 + wave * (32 * CIN_SRS);
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+      for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const u32x2 give = h ? pk[ct][k] : pk[ct][2 + k];
-        u32x2 got;
-        got[0] = (unsigned)__shfl_xor((int)give[0], 32, 64); got[1] = (unsigned)__shfl_xor((int)give[1], 32, 64);
-        const u32x2 own = h ? pk[ct][2 + k] : pk[ct][k];
-        const u32x4 out = h ? (u32x4){got[0], got[1], own[0], own[1]} : (u32x4){own[0], own[1], got[0], got[1]};
-        const int co0 = co_base + ct * 32 + 8 * (2 * h + k);
-        if (mok && co0 < a.Cout) *(u32x4*)(yp + co0) = out;
+        for (int q = 0; q < 4; ++q) *(u32x2*)(strip + nl * CIN_SRS + (32 * ct + 8 * q + 4 * h) * 2) = pk[ct][q];
+      __builtin_amdgcn_wave_barrier();
+      const int m0 = tile * 32, ch = lane & 7;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = (lane >> 3) + 8 * r;
+        const u32x4 out = *(const u32x4*)(strip + row * CIN_SRS + ch * 16);
+        if (m0 + row < a.M && co_base + ch * 8 < a.Cout) *(u32x4*)(a.y + (size_t)(m0 + row) * a.y_pitch + co_base + ch * 8) = out;
       }
+      __builtin_amdgcn_wave_barrier();
+    }
     // the prefetched batch becomes the current one
 #pragma unroll
     for (int s = 0; s < NK; ++s) cur[s] = nxt[s];
@@ -398,7 +404,7 @@ int s2p_thin_cin_fwd(const s2p_conv_desc* d, const void* x, const void* w, const
   const int cap = 768 / ncb > 32 ? 768 / ncb : 32;            // ~3 workgroups per CU: each stages 2*NK KiB of weights once
   if (gx > cap) gx = cap;
   const dim3 grid(gx, ncb);
-  const size_t lds = (size_t)2 * NK * 1024;
+  const size_t lds = (size_t)2 * NK * 1024 + 4 * 32 * CIN_SRS;      // weight fragments + one staging strip per wave
   if (d->KH == 4) hipLaunchKernelGGL(thin_cin_fwd_kernel<4>, grid, dim3(256), lds, st, a);
   else hipLaunchKernelGGL(thin_cin_fwd_kernel<3>, grid, dim3(256), lds, st, a);
   S2P_CHECK_LAUNCH("thin_cin_fwd_kernel");
