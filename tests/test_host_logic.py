@@ -76,6 +76,31 @@ def test_weight_gradient_workspace_plans_run_without_a_gpu():
     assert int(L.s2p_conv2d_wgrad_workspace(ctypes.byref(d), 64, 128)) == 0     # fp32 path: atomics, no scratch
 
 
+def test_fused_norm_dispatch_is_host_logic():
+    """`s2p_conv2d_mat_is_fused` is a plan-mode dry run of the conv dispatcher (no launch): which conv + InstanceNorm pairs of the train
+    step are ONE launch is decided on the host and can be pinned without a GPU -- the ResBlk convs with their MAT norms forward and
+    backward (conv_plane.hip), the PatchGAN 4x4 stride-1 layers forward and backward and the stride-2 layers forward on planes of up to
+    192 produced pixels (conv_planeg.hip); the 43x43 -> 22x22 layer, the stride-2 dgrads (sub-pixel phases), row-band planes and the
+    64x64 maps of the 256x256 rollout are two launches."""
+    import ctypes
+    from s2p_amd import ops
+    L = _lib.lib()
+
+    def fused(cin, cout, k, s, p, N, H, W, dgrad, gb):
+        d = ops.ConvGeom(cin, cout, k, s, p).desc(torch.bfloat16, N, H, W, cin, cin, cout)
+        return int(L.s2p_conv2d_mat_is_fused(ctypes.byref(d), dgrad, gb))
+
+    one = [(256, 256, 3, 1, 1, 64, 21, 21, 0, 1), (256, 256, 3, 1, 1, 64, 21, 21, 1, 1), (256, 512, 4, 1, 2, 64, 12, 12, 0, 0),
+           (256, 512, 4, 1, 2, 64, 12, 12, 1, 0), (256, 512, 4, 1, 2, 64, 7, 7, 0, 0), (128, 256, 4, 2, 2, 64, 22, 22, 0, 0),
+           (64, 128, 4, 2, 2, 64, 22, 22, 0, 0)]
+    two = [(64, 128, 4, 2, 2, 64, 43, 43, 0, 0), (128, 256, 4, 2, 2, 64, 22, 22, 1, 0), (64, 64, 3, 1, 1, 64, 84, 84, 0, 0),
+           (256, 256, 3, 1, 1, 16, 64, 64, 0, 1)]
+    for a in one:
+        assert fused(*a) == 1, a
+    for a in two:
+        assert fused(*a) == 0, a
+
+
 def test_struct_layouts_match_header():
     import ctypes
     assert ctypes.sizeof(_lib.ConvDesc) == 20 * 4
