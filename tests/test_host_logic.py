@@ -284,3 +284,35 @@ def test_lds_free_kernels_stay_lds_free():
     assert len(met) == 1, [names[k] for k in met]
     for k in lin + met:
         assert not a[k]["ds"] and not a[k]["lds_dma"], (names[k], dict(a[k]["ds"]))
+
+
+def test_rccl_sum_reduction_is_free_of_the_hazard_class():
+    """The data-parallel step runs RCCL's reduction kernels on the communication stream WHILE `wgrad_slab_kernel` / `conv_dma_kernel`
+    execute: the two aggressors of the co-residency hazard.  libs2p_hip.so is clean of the victim instruction
+    class by construction; RCCL is third-party code, so its gfx950 code object is audited here (no GPU: the code object is extracted
+    from the librccl.so torch loads with clang-offload-bundler, tests/tools/rccl_audit.py).  Finding (profiles/round5_rccl_isa_audit.txt):
+    RCCL's device code is per-(reduction, type) device functions behind a few generic kernels; the class -- `v_pk_fma_f32 ... op_sel`
+    -- occurs ONLY in the FuncPreMulSum<float> functions (ncclAvg / premul-sum).  The product reduces with SUM (the 1/world factor
+    is folded into Adam's grad_scale): FuncSum<float> is scalar `v_add_f32` in every ring function, and `v_pk_add_f32` WITHOUT a
+    swizzle in the tree functions (the form that was clean in round 4's probe beside both aggressors).  Hence:
+      * no instruction of the class in any function a SUM / fp32 or MAX / f64 all-reduce can reach, and
+      * the product never asks for AVG / PREMUL_SUM (s2p_amd/ is grepped), which would select the functions that DO carry it."""
+    import re
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import rccl_audit
+    so = rccl_audit.find_librccl()
+    if so is None or not os.path.exists(rccl_audit.LLVM + "/clang-offload-bundler"):
+        pytest.skip("no librccl.so / clang-offload-bundler in this environment")
+    rep = rccl_audit.product_report(so)
+    for key in rccl_audit.PRODUCT_REDUCTIONS:
+        r = rep["reductions"][key]
+        assert r["functions"] >= 20, (key, r["functions"])            # the symbol pattern still matches this RCCL build
+        assert not r["hazard"], (key, r["hazard"], r["functions_with_packed"])
+    ring = [n for n in rep["reductions"]["sum_f32"]["functions_with_packed"] if "runRing" in n]
+    assert not ring, ring                                               # ring SUM: scalar fp32 adds only
+    # the product's collectives: SUM (gradients), MAX (bench timing), broadcast, all_gather -- never AVG / PREMUL_SUM
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "s2p_amd")):
+        for fn in files:
+            if fn.endswith(".py"):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r"ReduceOp\.(AVG|PREMUL_SUM)|_make_nccl_premul_sum", src), os.path.join(dirpath, fn)
