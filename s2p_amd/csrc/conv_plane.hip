@@ -51,15 +51,34 @@ constexpr int PL_ERS = 144;                  // epilogue staging row: 64 co x 2 
 // reads, 8 no K loop, 16 clock stamps around the K loop, 64 coalesced (wrong) DMA sources; outputs are invalid for DIAG != 0.
 // MAT: the epilogue also InstanceNorm-alises the output plane it owns and applies the MAT / SPADE modulation + activation
 // (one more output tensor + the statistics buffer of norm.hip): conv -> IN -> modulate -> LeakyReLU in one launch.
-template <int PB, int WP, int DIAG, int MAT = 0>   // MAT: 0 plain conv, 1 + forward norm, 2 + backward of the norm that FED this dgrad's forward conv
+// GST (with MAT 1 / 2, gamma|beta maps present, Cin >= 256): the workgroup's gamma|beta rows -- the one operand of the norm tail
+// that no wave needs before the tail -- are fetched by LDS-DMA UNDER the K loop instead of by register loads behind it: the tail
+// then only computes and stores (the reads were 2/3 of the forward tail's HBM traffic and arrived cold, with every MFMA idle).
+// No VGPR is spent on them (the two register-prefetch forms of round 3 spilled or only warmed L2).  The whole 160 KB are used:
+//   [0, 32K)    plane buffer 0; from pair-step 4 of the LAST iteration (its last fragment read is in pair-step 3): rows 288..383
+//   [32K, 88K)  plane buffer 1 + weight ring; behind the loop: accumulator exchange in TWO rounds of 56 KB (one co block per wave
+//               and round), then the [pixel][co] staging rows at a 128-byte pitch with an XOR chunk swizzle, then reduce scratch
+//   [88K, 160K) gamma|beta rows 0..287, fetched during the three iterations before the last one (one piece per wave in
+//               pair-steps 2, 3, 4)
+// A row is 256 B, [gamma 128 B | beta 128 B] on even rows and [beta | gamma] on odd ones (the DMA's per-lane source address does
+// the swap): the tail's 16-lane ds_read_b128 groups then touch 16 distinct 16-byte slots.  Rows 384..440 (the seventh row of
+// each thread) still come through registers, loaded right behind the loop.  DMA accounting: the pieces are younger than every
+// weight / plane piece a later pair-step waits for only in the last iteration's tail, where the counted waits let them stay in
+// flight until the tail's first use (one vmcnt(0) + barrier there).
+template <int PB, int WP, int DIAG, int MAT = 0, int GST = 0>   // MAT: 0 plain conv, 1 + forward norm, 2 + backward of the norm that FED this dgrad's forward conv
 __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
   typedef __bf16 T;
+  static_assert(GST == 0 || (MAT != 0 && DIAG == 0 && PB == 7), "gamma|beta staging: fused-norm product kernels only");
   constexpr int BPIX = 4 * PB * 16;
   constexpr int NT = 4 * PB;                                   // accumulator tiles per wave
   constexpr int MERGE = 4 * NT * 1024;
   constexpr int MAIN = 2 * PL_PBUF + PL_RING * PL_WST;
   constexpr int EPI = BPIX * PL_ERS;
-  constexpr int SMEM = MERGE > MAIN ? (MERGE > EPI ? MERGE : EPI) : (MAIN > EPI ? MAIN : EPI);
+  constexpr int SMEM = GST ? 163840 : (MERGE > MAIN ? (MERGE > EPI ? MERGE : EPI) : (MAIN > EPI ? MAIN : EPI));
+  constexpr int XOFF = GST ? PL_PBUF : 0;                      // GST: exchange / staging / scratch region = buffer 1 + ring (56 KB)
+  constexpr int GB_B = MAIN;                                   // GST: gamma|beta rows 0..287
+  constexpr int GB_ROWS_B = (163840 - MAIN) / 256, GB_ROWS = GB_ROWS_B + 96;      // 288, 384 (= 6 x 64 rows; 96 rows in plane buffer 0)
+  static_assert(!GST || (GB_ROWS_B == 288 && BPIX * 128 == MAIN - PL_PBUF), "LDS map of the staged form");
   __shared__ __attribute__((aligned(1024))) char smem[SMEM];
   char* const pbase = smem;
   char* const wbase = smem + 2 * PL_PBUF;
@@ -119,6 +138,20 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
 #pragma unroll
   for (int t = 0; t < 9; ++t) wto[t] = a.wt[t] * a.Cin * 2;
 
+  // GST: gamma|beta pieces.  Piece pi = rows 4 pi .. 4 pi + 3; lane l lands at byte 16 l of the piece: row l >> 4, 128-byte half
+  // (l >> 3) & 1, chunk l & 7; the half holds beta iff half != row parity.  Wave w issues pieces w + 8 j.
+  i32x4 grs = xrs; int gvo = 0;
+  if constexpr (GST != 0) {
+    grs = s2p_make_rsrc(a.gb, (unsigned)a.N * (unsigned)HW * (unsigned)a.gb_pitch * 2u);
+    const int rl = lane >> 4, isb = ((lane >> 3) ^ rl) & 1;
+    gvo = (int)((((unsigned)img * HW + rl) * a.gb_pitch + isb * a.Cout + co_base + (lane & 7) * 8) * 2u);
+  }
+  auto issue_g = [&](int pi) {
+    if constexpr (GST != 0) {
+      const unsigned dst = pi < GB_ROWS_B / 4 ? (unsigned)(GB_B + pi * 1024) : (unsigned)((pi - GB_ROWS_B / 4) * 1024);
+      pl_dma16(grs, p_lds + dst, gvo, pi * 4 * a.gb_pitch * 2);     // (host: H * W >= 384, every staged row exists)
+    }
+  };
   const int nhs = a.Cin / 32;                                   // half-slabs (host guarantees Cin % 64 == 0)
   auto issue_plane2 = [&](int buf, int hs, int k0) {            // two of this wave's four pieces of half-slab hs
     const int so = hs * 64;
@@ -149,6 +182,12 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
     }
   }
   const int bA = (q >> 1) * 2048 + l15 * 32 + (q & 1) * 16;
+  int bAw = (int)(2 * PL_PBUF) + bA;                            // ring base + lane part: opaque, so that every fragment read is this
+  if constexpr (GST != 0) {                                     // register + a 16-bit immediate (the three loop bodies of the staged
+    asm volatile("" : "+v"(bAw));                               // form otherwise hoist one address register per (stage, block))
+#pragma unroll
+    for (int j = 0; j < PB; ++j) asm volatile("" : "+v"(bB[j]));
+  }
   f32x4v acc[4][PB];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -162,7 +201,7 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
   // of those instructions.  Set 0 runs the even K steps, set 1 the odd ones (ring stages of the same parity).
   auto read_a = [&](auto uc, auto ic, bf16x8 (&fa)[4]) {
     constexpr int u = decltype(uc)::value % 18, i = decltype(ic)::value;
-    if constexpr ((DIAG & 4) == 0) fa[i] = *(const bf16x8*)(wbase + (u % PL_RING) * PL_WST + i * 512 + bA);
+    if constexpr ((DIAG & 4) == 0) fa[i] = *(const bf16x8*)(smem + (u % PL_RING) * PL_WST + i * 512 + bAw);
   };
   auto read_b = [&](auto uc, auto jc, bf16x8 (&fb)[PB]) {
     constexpr int u = decltype(uc)::value % 18, j = decltype(jc)::value;
@@ -183,10 +222,18 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
   // top of pair-step U: everything this wave issued before the previous pair-step has landed (what it issued IN the previous
   // pair-step -- one weight piece, plus two plane pieces after U = 0, 1, 5, 6 -- may still be in flight), its own LDS
   // reads have returned (another wave's DMA may overwrite what they read once the barrier is passed), then the barrier
+  // GST: ONE loop body and NO branch in it (a second copy of the body made the register allocator spill accumulators, wave-uniform
+  // branches inside it made it spill the DMA offsets and reload them behind vmcnt(0)); what differs between iterations is chosen
+  // by scalar selects, and every iteration issues the same number of DMAs per pair-step, so the counted waits are compile-time
+  // constants.  Every iteration issues one gamma|beta piece per wave in pair-steps 2, 3, 4: rows 0..287 over the three iterations
+  // before the last; earlier iterations and the last one re-issue a piece that is already there (same bytes to the same place).
+  // In the LAST iteration the four plane slots of pair-steps 5, 6 -- dummies without the staging, which would zero plane buffer 0
+  // -- carry rows 288..383 into that buffer (three pieces + one re-issue).
   auto sync_top = [&](auto Uc) {
     constexpr int UP = (decltype(Uc)::value + 8) % 9;
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (UP == 0 || UP == 1 || UP == 5 || UP == 6) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+    else if constexpr (GST != 0 && (UP == 2 || UP == 3 || UP == 4)) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -218,6 +265,21 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
     if constexpr ((DIAG & 16) != 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
     if constexpr ((DIAG & 128) != 0) ph[1] = __builtin_amdgcn_s_memrealtime();
     for (int k2 = 0; k2 < nloop; k2 += 2) {                     // two half-slabs = 18 K steps = 9 pair-steps per iteration
+      const int left = (nloop - k2) >> 1;                       // GST: iterations left, this one included (host: at least 4 in all)
+      const bool last = GST != 0 && left == 1;
+      int gj = (4 - left) * 3;                                  // GST: first of this iteration's three pieces w + 8 j (clamped: a re-issue)
+      gj = gj < 0 ? 0 : (gj > 6 ? 6 : gj);
+      // GST, pair-steps 5 / 6: plane piece k of the next half-slab, or (last iteration) gamma|beta piece 72 + w + 8 min(k, 2)
+      auto issue_p0 = [&](int k) {
+        if constexpr (GST != 0) {
+          const int pi = GB_ROWS_B / 4 + wave + 8 * (k > 2 ? 2 : k);
+          i32x4 rs;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) rs[c] = last ? grs[c] : xrs[c];
+          pl_dma16(rs, p_lds + (last ? (unsigned)((pi - GB_ROWS_B / 4) * 1024) : hdst[k]), last ? gvo : hv[k],
+                   last ? pi * 4 * a.gb_pitch * 2 : (k2 + 2) * 64);
+        }
+      };
       pl_static_for<0, 9>([&](auto Uc) {
         constexpr int U = decltype(Uc)::value;
         constexpr int u = 2 * U + SET;
@@ -238,15 +300,24 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
         mfma4(I1{}, fa, fb);
         __builtin_amdgcn_sched_barrier(0);
         read_b(un{}, I0{}, nb); read_b(un{}, I1{}, nb);
-        if constexpr ((DIAG & 1) == 0) { constexpr int u2 = u + 6; issue_w(u2 % PL_RING, wto[u2 % 9], k2 + u2 / 9); }
+        if constexpr ((DIAG & 1) == 0) {
+          constexpr int u2 = u + 6;
+          issue_w(u2 % PL_RING, wto[u2 % 9], k2 + u2 / 9);
+        }
         mfma4(I2{}, fa, fb);
         __builtin_amdgcn_sched_barrier(0);
         read_b(un{}, I2{}, nb); read_b(un{}, I3{}, nb);
         if constexpr ((DIAG & 1) == 0) {
           if constexpr (U == 0) issue_plane2(1, k2 + 1, 0);     // buffer 1 was last read in pair-step 7 of the previous iteration
           if constexpr (U == 1) issue_plane2(1, k2 + 1, 2);
-          if constexpr (U == 5) issue_plane2(0, k2 + 2, 0);     // buffer 0 was last read in pair-step 3
-          if constexpr (U == 6) issue_plane2(0, k2 + 2, 2);
+          if constexpr (GST != 0 && U >= 2 && U <= 4) issue_g(wave + 8 * (gj + U - 2));
+          if constexpr (GST == 0) {
+            if constexpr (U == 5) issue_plane2(0, k2 + 2, 0);   // buffer 0 was last read in pair-step 3
+            if constexpr (U == 6) issue_plane2(0, k2 + 2, 2);
+          } else {
+            if constexpr (U == 5) { issue_p0(0); issue_p0(1); }
+            if constexpr (U == 6) { issue_p0(2); issue_p0(3); }
+          }
         }
         mfma4(I3{}, fa, fb);
         __builtin_amdgcn_sched_barrier(0);
@@ -284,19 +355,39 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
 
   // ---- add the two partial accumulators of a wave pair through LDS: the pair exchanges halves (set 0 ends up with the sums
   //      of co blocks 0-1, set 1 with co blocks 2-3), so all eight waves share the epilogue -----------------------------------
+  // staging row of pixel px, 16-byte chunk c (8 channels): 144-byte rows, or (GST) 128-byte rows with the chunk index XOR px & 7
+  auto srow = [&](int px, int c) -> char* {
+    if constexpr (GST != 0) return smem + XOFF + px * 128 + ((c ^ (px & 7)) << 4);
+    else return smem + px * PL_ERS + c * 16;
+  };
   auto finish = [&](auto ibc) {
     constexpr int IB = decltype(ibc)::value;                    // first co block this wave keeps; it hands over the other two
-    char* mb = smem + (size_t)(wq * NT) * 1024 + lane * 16;
+    if constexpr (GST == 0) {
+      char* mb = smem + (size_t)(wq * NT) * 1024 + lane * 16;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < PB; ++j) *(f32x4v*)(mb + ((2 - IB + i) * PB + j) * 1024) = acc[2 - IB + i][j];
-    __syncthreads();
+        for (int j = 0; j < PB; ++j) *(f32x4v*)(mb + ((2 - IB + i) * PB + j) * 1024) = acc[2 - IB + i][j];
+      __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < PB; ++j) acc[IB + i][j] += *(const f32x4v*)(mb + ((IB + i) * PB + j) * 1024);
-    __syncthreads();                                            // the staging rows below overlap the exchange area
+        for (int j = 0; j < PB; ++j) acc[IB + i][j] += *(const f32x4v*)(mb + ((IB + i) * PB + j) * 1024);
+      __syncthreads();                                          // the staging rows below overlap the exchange area
+    } else {
+      // two rounds of one co block per wave: a wave pair shares 2 x 7 KB; set 0 writes slot 1 and reads slot 0, set 1 the reverse
+      char* mb = smem + XOFF + (size_t)(wq * 2 * PB) * 1024 + lane * 16;
+      constexpr int WS = IB == 0 ? 1 : 0, RS = 1 - WS;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < PB; ++j) *(f32x4v*)(mb + (WS * PB + j) * 1024) = acc[2 - IB + i][j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PB; ++j) acc[IB + i][j] += *(const f32x4v*)(mb + (RS * PB + j) * 1024);
+        __syncthreads();                                        // (the last one: the staging rows below overlap the exchange area)
+      }
+    }
     if constexpr ((DIAG & 128) != 0) ph[3] = __builtin_amdgcn_s_memrealtime();
     // bias + activation in registers, then [pixel][co] staging rows (transpose through LDS)
     const float* bias = a.bias ? a.bias + (size_t)g * a.Cout + co_base : nullptr;
@@ -314,7 +405,7 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
           const int px = (wq * PB + j) * 16 + l15;
           const f32x4v v = acc[IB + i][j];
           bf16x4 o = {(__bf16)f(v[0] + bv[i][0]), (__bf16)f(v[1] + bv[i][1]), (__bf16)f(v[2] + bv[i][2]), (__bf16)f(v[3] + bv[i][3])};
-          *(bf16x4*)(smem + px * PL_ERS + (16 * (IB + i) + 4 * q) * 2) = o;
+          *(bf16x4*)(srow(px, 2 * (IB + i) + (q >> 1)) + (q & 1) * 8) = o;
         }
     };
     if (a.act == S2P_ACT_TANH) stage_out([](float v) { return tanhf(v); });
@@ -337,7 +428,7 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
   // one (pixel row, 8-channel chunk) item of the output: staged value (+ residual / producer-activation-gradient epilogue)
   auto out_chunk = [&](int row, int ch, size_t go) {
     Chunk<T> c;
-    c.raw = *(const u32x4*)(smem + row * PL_ERS + ch * 16);
+    c.raw = *(const u32x4*)srow(row, ch);
     if (a.epi != S2P_EPI_STORE) {
       Chunk<T> x, x2;
       x.raw = *(const u32x4*)(auxg + go);
@@ -367,16 +458,23 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
     constexpr int MAXR = BPIX / 64;
     const int ch = tid & 7, r0 = tid >> 3;
     const T* gbb = a.gb ? (const T*)a.gb + (size_t)img * HW * a.gb_pitch + co_base + ch * 8 : nullptr;
-    Chunk<T> xv[MAXR], gv[MAXR], bv[MAXR];
+    constexpr int KG0 = GST ? GB_ROWS / 64 : 0;                  // rows r0 + 64 k, k < KG0: gamma | beta are staged in LDS
+    Chunk<T> xv[MAXR], gv[MAXR - KG0], bv[MAXR - KG0];
 #pragma unroll
-    for (int k = 0; k < MAXR; ++k) {                             // gamma / beta first: their latency runs under the rest
+    for (int k = KG0; k < MAXR; ++k) {                           // gamma / beta first: their latency runs under the rest
       const int row = r0 + 64 * k;
-      gv[k].raw = (u32x4){0u, 0u, 0u, 0u}; bv[k].raw = gv[k].raw;
+      gv[k - KG0].raw = (u32x4){0u, 0u, 0u, 0u}; bv[k - KG0].raw = gv[k - KG0].raw;
       if (gbb && row < HW) {
-        gv[k].raw = *(const u32x4*)(gbb + (size_t)row * a.gb_pitch);
-        bv[k].raw = *(const u32x4*)(gbb + (size_t)row * a.gb_pitch + a.Cout);
+        gv[k - KG0].raw = *(const u32x4*)(gbb + (size_t)row * a.gb_pitch);
+        bv[k - KG0].raw = *(const u32x4*)(gbb + (size_t)row * a.gb_pitch + a.Cout);
       }
     }
+    // GST: LDS address of this thread's gamma chunk of row r0 (beta: ^ 128); row r0 + 64 k is 64 rows = 16 KB further (r0 + 64 k
+    // keeps r0's parity), rows from 288 on live in plane buffer 0
+    auto gst_row = [&](int k) -> int {
+      const int row = r0 + 64 * k;
+      return (row < GB_ROWS_B ? GB_B + row * 256 : (row - GB_ROWS_B) * 256) + ((r0 & 1) << 7) + ch * 16;
+    };
 #pragma unroll
     for (int k = 0; k < MAXR; ++k) {
       const int row = r0 + 64 * k;
@@ -388,8 +486,8 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
       }
     }
     __syncthreads();                                            // the staging rows are dead: LDS is scratch from here on
-    float* red = (float*)smem;                                  // [8 waves][64]
-    float* cst = (float*)smem + 8 * 64;                         // [4][64]: plane sum / M2, then 1 + gamma_st, beta_st
+    float* red = (float*)(smem + XOFF);                         // [8 waves][64]
+    float* cst = red + 8 * 64;                                  // [4][64]: plane sum / M2, then 1 + gamma_st, beta_st
     auto plane_sum = [&](float (&v)[8], int slot) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -451,10 +549,12 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
     for (int k = 0; k < MAXR; ++k) {
       const int row = r0 + 64 * k;
       if (row >= HW) break;
-      Chunk<T> o0;
+      Chunk<T> o0, gk, bk;
+      if (k < KG0) { const int go = gst_row(k); gk.raw = *(const u32x4*)(smem + go); bk.raw = *(const u32x4*)(smem + (go ^ 128)); }
+      else { gk = gv[k < KG0 ? 0 : k - KG0]; bk = bv[k < KG0 ? 0 : k - KG0]; }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float gg = gs[e] + gv[k].get(e), bb = bs[e] + bv[k].get(e);
+        const float gg = gs[e] + gk.get(e), bb = bs[e] + bk.get(e);
         const float xh = (xv[k].get(e) - mean[e]) * rstd[e];
         const float yv = __builtin_fmaf(xh, gg, bb);              // (norm.hip: mat_value)
         o0.set(e, yv > 0.f ? yv : yv * nns);
@@ -472,20 +572,31 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
     const int ch = tid & 7, r0 = tid >> 3, lc = co_base + ch * 8;
     const T* xb = (const T*)a.xn + (size_t)img * HW * a.xn_pitch + lc;
     const T* gbb = a.gb ? (const T*)a.gb + (size_t)img * HW * a.gb_pitch + lc : nullptr;
-    Chunk<T> xv[MAXR], gv[MAXR], bv[MAXR], dv[MAXR];
+    constexpr int KG0 = GST ? GB_ROWS / 64 : 0;                  // rows r0 + 64 k, k < KG0: gamma | beta are staged in LDS
+    Chunk<T> xv[MAXR], gv[MAXR - KG0], bv[MAXR - KG0], dv[MAXR];
 #pragma unroll
     for (int k = 0; k < MAXR; ++k) {
       const int row = r0 + 64 * k;
-      xv[k].raw = (u32x4){0u, 0u, 0u, 0u}; gv[k].raw = xv[k].raw; bv[k].raw = xv[k].raw; dv[k].raw = xv[k].raw;
+      xv[k].raw = (u32x4){0u, 0u, 0u, 0u}; dv[k].raw = xv[k].raw;
+      if (k >= KG0) { gv[k < KG0 ? 0 : k - KG0].raw = xv[k].raw; bv[k < KG0 ? 0 : k - KG0].raw = xv[k].raw; }
       if (row < HW) {
         xv[k].raw = *(const u32x4*)(xb + (size_t)row * a.xn_pitch);
-        if (gbb) { gv[k].raw = *(const u32x4*)(gbb + (size_t)row * a.gb_pitch); bv[k].raw = *(const u32x4*)(gbb + (size_t)row * a.gb_pitch + a.Cout); }
-        dv[k].raw = *(const u32x4*)(smem + row * PL_ERS + ch * 16);     // rows beyond HW stay zero: they add nothing to the sums
+        if (k >= KG0 && gbb) { gv[k < KG0 ? 0 : k - KG0].raw = *(const u32x4*)(gbb + (size_t)row * a.gb_pitch); bv[k < KG0 ? 0 : k - KG0].raw = *(const u32x4*)(gbb + (size_t)row * a.gb_pitch + a.Cout); }
+        dv[k].raw = *(const u32x4*)srow(row, ch);                // rows beyond HW stay zero: they add nothing to the sums
       }
     }
+    auto gst_row = [&](int k) -> int {                          // (see the forward tail)
+      const int row = r0 + 64 * k;
+      return (row < GB_ROWS_B ? GB_B + row * 256 : (row - GB_ROWS_B) * 256) + ((r0 & 1) << 7) + ch * 16;
+    };
+    // gamma | beta chunk of this thread's row r0 + 64 k: from the staged rows (a masked row reads some other row: its dv is zero)
+    auto load_gb = [&](int k, Chunk<T>& gk, Chunk<T>& bk) {
+      if (k < KG0) { const int go = gst_row(k); gk.raw = *(const u32x4*)(smem + go); bk.raw = *(const u32x4*)(smem + (go ^ 128)); }
+      else { gk = gv[k < KG0 ? 0 : k - KG0]; bk = bv[k < KG0 ? 0 : k - KG0]; }
+    };
     __syncthreads();                                            // the staging rows are dead: LDS is scratch from here on
-    float* red = (float*)smem;                                  // [4 sums][8 waves][64]
-    float* cst = (float*)smem + 4 * 8 * 64;                     // [6][64]: mean, rstd, 1 + gamma_st, beta_st, s1 / HW, s2 / HW
+    float* red = (float*)(smem + XOFF);                         // [4 sums][8 waves][64]
+    float* cst = red + 4 * 8 * 64;                              // [6][64]: mean, rstd, 1 + gamma_st, beta_st, s1 / HW, s2 / HW
     if (tid < 64) {
       const int c = co_base + tid;
       // merge the per-split partial moments (norm.hip: mean_rstd; S = 1 when a fused forward kernel wrote them)
@@ -506,6 +617,38 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
     const float gneg = a.n_act == S2P_ACT_RELU ? 0.f : (a.n_act == S2P_ACT_LRELU ? a.n_slope : 1.f);
     unsigned long long posmask = 0ull;                          // activation branch per (row k, element e): pass 2 reuses pass 1's
     // ---- pass 1: the four plane sums
+    if constexpr (GST != 0) {
+      // rows outermost (one LDS read of the staged gamma | beta chunk per row); every sum still adds its rows in ascending order
+      float q0[8], q1[8], q2[8], q3[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { q0[e] = 0.f; q1[e] = 0.f; q2[e] = 0.f; q3[e] = 0.f; }
+#pragma unroll
+      for (int k = 0; k < MAXR; ++k) {
+        Chunk<T> gk, bk;
+        load_gb(k, gk, bk);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int cl = ch * 8 + e;
+          const float gg = cst[128 + cl] + gk.get(e), bb = cst[192 + cl] + bk.get(e);
+          const float xh = (xv[k].get(e) - cst[cl]) * cst[64 + cl];
+          const float yv = __builtin_fmaf(xh, gg, bb);          // (norm.hip: mat_value -- the forward's rounding)
+          const bool pos = yv > 0.f;
+          posmask |= pos ? (1ull << (k * 8 + e)) : 0ull;
+          const float dy = dv[k].get(e) * (pos ? 1.f : gneg);
+          const float dxh = dy * gg;
+          q0[e] += dxh; q1[e] += dxh * xh; q2[e] += dy * xh; q3[e] += dy;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int cl = ch * 8 + e;
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) {
+          q0[e] += __shfl_xor(q0[e], o, 64); q1[e] += __shfl_xor(q1[e], o, 64); q2[e] += __shfl_xor(q2[e], o, 64); q3[e] += __shfl_xor(q3[e], o, 64);
+        }
+        if (lane < 8) { red[(0 * 8 + wave) * 64 + cl] = q0[e]; red[(1 * 8 + wave) * 64 + cl] = q1[e]; red[(2 * 8 + wave) * 64 + cl] = q2[e]; red[(3 * 8 + wave) * 64 + cl] = q3[e]; }
+      }
+    } else
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int cl = ch * 8 + e;
@@ -550,11 +693,12 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
     for (int k = 0; k < MAXR; ++k) {
       const int row = r0 + 64 * k;
       if (row >= HW) break;
-      Chunk<T> o0, o1, o2;
+      Chunk<T> o0, o1, o2, gk, bk;
+      load_gb(k, gk, bk);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int cl = ch * 8 + e;
-        const float m = cst[cl], r = cst[64 + cl], gg = cst[128 + cl] + gv[k].get(e), s1 = cst[256 + cl], s2 = cst[320 + cl];
+        const float m = cst[cl], r = cst[64 + cl], gg = cst[128 + cl] + gk.get(e), s1 = cst[256 + cl], s2 = cst[320 + cl];
         const float xh = (xv[k].get(e) - m) * r;
         const float dy = dv[k].get(e) * (((posmask >> (k * 8 + e)) & 1ull) ? 1.f : gneg);
         const float dxh = dy * gg;
@@ -833,8 +977,18 @@ int s2p_conv_plane_launch(PlaneArgs& a, int groups, hipStream_t st) {
     S2P_CHECK_LAUNCH("conv_plane_pair_kernel");
     return 0;
   }
-  if (a.y2 && a.xn) { hipLaunchKernelGGL((conv_plane_kernel<7, 22, 0, 2>), grid, dim3(512), 0, st, a); S2P_CHECK_LAUNCH("conv_plane_kernel(mat bwd)"); return 0; }
-  if (a.y2) { hipLaunchKernelGGL((conv_plane_kernel<7, 22, 0, 1>), grid, dim3(512), 0, st, a); S2P_CHECK_LAUNCH("conv_plane_kernel(mat)"); return 0; }
+  // gamma|beta maps present and at least four loop iterations (Cin >= 256): the maps' rows are staged by LDS-DMA under the K loop
+  const bool gst = a.y2 && a.gb && a.Cin >= 256 && a.H * a.W >= 384 && (long long)a.N * a.H * a.W * a.gb_pitch * 2 < (1ll << 31) && !S2P_DIAG_SWITCH(7);
+  if (a.y2 && a.xn) {
+    if (gst) hipLaunchKernelGGL((conv_plane_kernel<7, 22, 0, 2, 1>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((conv_plane_kernel<7, 22, 0, 2>), grid, dim3(512), 0, st, a);
+    S2P_CHECK_LAUNCH("conv_plane_kernel(mat bwd)"); return 0;
+  }
+  if (a.y2) {
+    if (gst) hipLaunchKernelGGL((conv_plane_kernel<7, 22, 0, 1, 1>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((conv_plane_kernel<7, 22, 0, 1>), grid, dim3(512), 0, st, a);
+    S2P_CHECK_LAUNCH("conv_plane_kernel(mat)"); return 0;
+  }
   hipLaunchKernelGGL((conv_plane_kernel<7, 22, 0>), grid, dim3(512), 0, st, a);
   S2P_CHECK_LAUNCH("conv_plane_kernel");
   return 0;
