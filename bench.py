@@ -64,7 +64,7 @@ def spade_resblk_aggregate(recs, N, HW):
     launches = 0
     for r in recs:
         k = r["kind"]
-        if k in ("fwd", "dgrad", "wgrad") and tuple(r["shape"]) in conv_shapes:
+        if k in ("fwd", "dgrad", "wgrad") and tuple(r["shape"]) in conv_shapes and r.get("net") == "G":     # (VGG conv3_x has the ResBlk conv's shape)
             w = 0.5 if k == "fwd" else 1.0
             flops += w * r["flops"]; t_mfma += w * ms(r); launches += w
         elif k.startswith("norm") and tuple(r["shape"][:4]) == (N, h, h, 256) and r["shape"][4] == 1 or \
@@ -79,10 +79,63 @@ def spade_resblk_aggregate(recs, N, HW):
                 frac=round(flops / (tot * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
                 mfma_only_frac=round(flops / (t_mfma * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
                 norm_hbm_tbps=round(nbytes / (t_norm * 1e-3) / 1e12, 2) if t_norm > 0 else None,
-                includes="6 blocks: 12 conv3x3 256->256 (fwd, dgrad, wgrad), grouped gamma/beta conv 12x(128->512) (fwd, dgrad, wgrad), "
+                includes="generator launches only (records are tagged with their network; VGG conv3_x, same shape as the block convs, is excluded). "
+                         "6 blocks: 12 conv3x3 256->256 (fwd, dgrad, wgrad), grouped gamma/beta conv 12x(128->512) (fwd, dgrad, wgrad), "
                          "shared conv 3->1536 (fwd, wgrad), the 12 MAT norms forward and backward -- 11 forward and all 12 backward norms run "
                          "inside conv launches (s2p_conv2d_fwd_mat / s2p_conv2d_dgrad_mat: their HBM-bound tails are in mfma_ms), norm_ms is "
                          "what is left as separate launches; the fp32 state affine is excluded")
+
+
+def hbm_rows(batch, size, version):
+    """HBM side of the roofline, from the evidence committed under profiles/ (counters cannot be collected inside this process):
+    per (kernel, grid) the HBM bytes per launch of the latest rocprofv3 --pmc passes (FETCH_SIZE x 2 per MI355X_MICROARCH.md, WRITE_SIZE)
+    divided by that kernel's serial-stream dispatch time from the kernel trace of the same round.  `rows`: the three kernels without
+    matrix work (MFMA-busy share < 2 %) that cost the step the most; `read_amplification`: MFMA kernels known to re-read their input
+    (HBM read bytes against the input tensor's size).  Reported only while the files were measured on the loaded library version."""
+    import csv, glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_traffic.json")))
+    if not cands:
+        return None
+    tj = json.load(open(cands[-1]))
+    meta = tj.get("_meta", {})
+    if meta.get("s2p_version") != version:
+        raise RuntimeError("%s was measured on library version %s, this run loads %s: hbm rows not reported" % (
+            os.path.basename(cands[-1]), meta.get("s2p_version"), version))
+    summ = cands[-1].replace("_pmc_traffic.json", "_serial_kernel_summary.csv")
+    pmc = {}
+    for k, v in tj.items():
+        if k != "_meta" and "hbm_read_bytes" in v and "hbm_write_bytes" in v:
+            n, g_ = [x.strip() for x in k.split("|")][:2]
+            pmc[(n, g_.replace("grid ", ""))] = v
+    joined = []
+    for r in csv.DictReader(open(summ)):
+        gx = [int(x) for x in r["grid"].split("x")]
+        v = pmc.get((r["kernel"], str(gx[0]))) or pmc.get((r["kernel"], str(gx[0] * gx[1] * gx[2])))
+        if v is None:
+            continue
+        by, us = v["hbm_read_bytes"] + v["hbm_write_bytes"], float(r["avg_us"])
+        joined.append(dict(kernel=r["kernel"][:80], grid=r["grid"], us_per_step=float(r["us_per_step"]), avg_us=us,
+                           hbm_read_mb=round(v["hbm_read_bytes"] / 1e6, 2), hbm_write_mb=round(v["hbm_write_bytes"] / 1e6, 2),
+                           achieved_gbs=round(by / us / 1e3, 1), frac=round(by / us / 1e3 / HBM_PEAK_GBS, 4),
+                           mfma_busy_share=round(v.get("mfma_util", 0.0), 4)))
+    rows = sorted([j for j in joined if j["mfma_busy_share"] < 0.02 and j["hbm_read_mb"] + j["hbm_write_mb"] >= 8.0],
+                  key=lambda j: -j["us_per_step"])[:3]
+    # input re-reads of two MFMA kernels (VERDICT r4): VGG conv1_2 as 2-row bands, the decoder's transposed conv as four sub-pixel phases
+    q = size // 2
+    known = [("conv_planeg_kernel<3, 3, 3, 384, 6, 0, false, false>", str(batch * (size // 2) * 512) + "x1x1", batch * size * size * 64 * 2 / 1e6,
+              "VGG conv1_2 64->64 at %dx%d as 2-row bands (input %dx%dx64)" % (size, size, size, size)),
+             ("conv_dma_kernel<64, 128, 2, 2>", None, batch * q * q * 128 * 2 / 1e6,
+              "decoder transposed conv 128->64 %d->%d (input %dx%dx128), four sub-pixel phases" % (q, size, q, q))]
+    amp = []
+    for name, grid, in_mb, what in known:
+        m = [j for j in joined if j["kernel"] == name and (grid is None or j["grid"] == grid)]
+        if m:
+            j = max(m, key=lambda j: j["hbm_read_mb"])
+            amp.append(dict(kernel=name, grid=j["grid"], layer=what, hbm_read_mb=j["hbm_read_mb"], input_mb=round(in_mb, 2),
+                            read_amplification=round(j["hbm_read_mb"] / in_mb, 2), avg_us=j["avg_us"]))
+    return dict(peak=HBM_PEAK_GBS, unit="GB/s", rows=rows, read_amplification=amp,
+                source="%s + %s" % (os.path.relpath(cands[-1], ROOT), os.path.relpath(summ, ROOT)), commit=meta.get("commit"),
+                s2p_version=meta.get("s2p_version"))
 
 
 def cpu_baseline(args, state_dim):
@@ -394,6 +447,12 @@ def main():
                         avg_launch_us=round(tot_ms * 1e3 / max(len(recs), 1), 2),
                         by_kind={k: dict(gflop=round(v[0] / 1e9, 1), ms=round(v[1], 3), launches=v[2],
                                          tflops=round(v[0] / (v[1] * 1e-3) / 1e12, 2)) for k, v in by_kind.items()})
+        try:
+            from s2p_amd import _lib as _l2
+            roofline["hbm_rows"] = hbm_rows(args.batch, args.size, _l2.lib().s2p_version())
+        except Exception as e:      # evidence files absent / of another library version: null, never a failed bench
+            print("[bench] hbm_rows: %s" % e, file=sys.stderr)
+            roofline["hbm_rows"] = None
 
     devices = sorted(set(dp.all_gather_ints(torch.cuda.current_device()))) if dp.active else None      # (a collective: every rank)
     cpu = None

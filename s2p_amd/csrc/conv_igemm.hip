@@ -45,7 +45,7 @@ struct GatherArgs {
   int tap[MAX_TAPS];   // (wt << 16) | ((dx & 0xff) << 8) | (dy & 0xff)
   // merged sub-pixel phases (strided dgrad / transposed fwd on the LDS-DMA kernel): blockIdx.z selects a record that
   // overrides the per-phase fields above, so the s*s short GEMMs of one layer are ONE launch
-  int nphase;
+  int nphase, phase_fast;
   struct Phase { int Qh, Qw, M, oy0, ox0, T, Ktot, npix_tiles; int tap[PHASE_TAPS]; } ph[MAX_PHASES];
 };
 
@@ -547,13 +547,19 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const GatherArgs a) {
   // per-phase problem fields (block-uniform)
   int pQh = a.Qh, pQw = a.Qw, pM = a.M, poy0 = a.oy0, pox0 = a.ox0, pT = a.T, pKtot = a.Ktot, pnpt = a.npix_tiles;
   const int* ptap = a.tap;
+  int bid = blockIdx.x;
   if (a.nphase > 0) {
-    const GatherArgs::Phase& P = a.ph[blockIdx.z];
+    // merged sub-pixel phases.  phase_fast: the phase is the FASTEST index inside an XCD's share of the 1-D grid (blocks b, b + 8,
+    // ... share an XCD under the observed round-robin placement: speed only), so the phases of a pixel tile -- which gather the SAME
+    // input rows -- run side by side on one XCD and the rows come from HBM once; with the phase in blockIdx.z (round 1) each phase
+    // was a pass of its own over the input (4.05 x the input in L2 misses on the decoder's transposed conv)
+    int pz = blockIdx.z;
+    if (a.phase_fast) { const int xcd = bid & 7, k = bid >> 3; pz = k % a.nphase; bid = ((k / a.nphase) << 3) | xcd; }
+    const GatherArgs::Phase& P = a.ph[pz];
     pQh = P.Qh; pQw = P.Qw; pM = P.M; poy0 = P.oy0; pox0 = P.ox0; pT = P.T; pKtot = P.Ktot; pnpt = P.npix_tiles;
     ptap = P.tap;
   }
   int nblk = pnpt * a.nco_tiles;
-  int bid = blockIdx.x;
   if (bid >= nblk) return;                            // phases differ in size; the grid is sized for the largest
   {
     int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, k = bid >> 3;
@@ -1479,6 +1485,11 @@ static int run_scatter(const Geo& G, const void* x, const void* w, const float* 
         const int BCO = a.Cst > 64 ? 128 : 64;
         a.nco_tiles = cdiv(a.Cst, BCO);
         dim3 grid(max_npt * a.nco_tiles, G.groups, np);
+        // phase-fastest 1-D grid (see conv_dma_kernel) for the 64-row weight tile: HBM reads of the decoder's 128 -> 64 transposed conv
+        // 117 -> 30 MB (= its input once) at the same duration, the 64 -> 128 stride-2 dgrad 55 -> 33 MB and 6 % faster; the 128-row tile
+        // keeps the phase in blockIdx.z (measured: 41 -> 48 us on the 128 -> 256 stride-2 dgrad with the phases interleaved)
+        a.phase_fast = (BCO == 64 && !S2P_DIAG_SWITCH(10)) ? 1 : 0;
+        if (a.phase_fast) grid = dim3(((max_npt * a.nco_tiles + 7) / 8) * 8 * np, G.groups, 1);
         if (BCO == 128) hipLaunchKernelGGL((conv_dma_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((conv_dma_kernel<64, 128, 2, 2>), grid, dim3(256), 0, st, a);
         S2P_CHECK_LAUNCH("conv_dma_kernel(phases)");

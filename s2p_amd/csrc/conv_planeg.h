@@ -30,7 +30,7 @@ struct PlaneGArgs {
   const float* gbst; int gbst_pitch;
   float* stats; int n_act; float n_slope, eps;
   const void* xn; int xn_pitch; void* dgb; int dgb_pitch; float* dgbst; int dgbst_pitch; const void* res; int res_pitch;
-  int nco;
+  int nco, img_xcd;               // set by the launcher: Cout / 64; all row bands of an image on one XCD
   int R, nbands;                     // produced rows per workgroup and bands per image (R = Ho, 1: the whole plane)
   int shape;                         // index of the instantiated tile shape (set by s2p_conv_planeg_setup)
 };

@@ -92,14 +92,20 @@ __global__ __launch_bounds__(512, ((PB <= 3 && (TY == 3 || PG_OCC4_ALL)) ? 4 : 2
   const int set = wave >> 2, wq = wave & 3;
   const int q = lane >> 4, l15 = lane & 15;
   const int g = blockIdx.y;
-  // workgroup -> (plane = image x row band, co slab): the nco slabs of one plane run back to back on ONE XCD
-  int pl, cs;
+  // workgroup -> (plane = image x row band, co slab): the nco slabs of one plane run back to back on ONE XCD, and so do ALL the
+  // bands of an image (blocks b, b + 8, ... share an XCD under the observed round-robin placement: speed only): neighbouring
+  // bands read each other's halo rows, which are then L2 hits instead of a second and third HBM read (round 4 dealt the bands
+  // round-robin over the XCDs: VGG conv1_2 as 2-row bands read its input 3.0 times from HBM)
+  int img, band, cs;
   {
-    const int bid = blockIdx.x, nco = a.nco, np = a.N * a.nbands;
-    if ((np & 7) == 0) { const int xcd = bid & 7, k = bid >> 3; cs = k % nco; pl = (k / nco) * 8 + xcd; }
-    else { cs = bid % nco; pl = bid / nco; }
+    const int bid = blockIdx.x, nco = a.nco;
+    if (a.img_xcd) {
+      const int xcd = bid & 7, k = bid >> 3;
+      cs = k % nco; band = (k / nco) % a.nbands; img = (k / (nco * a.nbands)) * 8 + xcd;
+    } else if (((a.N * a.nbands) & 7) == 0) {
+      const int xcd = bid & 7, k = bid >> 3; cs = k % nco; const int pl = (k / nco) * 8 + xcd; img = pl / a.nbands; band = pl - img * a.nbands;
+    } else { cs = bid % nco; const int pl = bid / nco; img = pl / a.nbands; band = pl - img * a.nbands; }
   }
-  const int img = pl / a.nbands, band = pl - img * a.nbands;
   const int r0 = band * a.R;                                   // first produced row of this band (0 when the plane is the whole image)
   const int co_base = cs * 64;
   const int rows_here = a.Ho - r0 < a.R ? a.Ho - r0 : a.R;
@@ -659,6 +665,7 @@ static void pg_launch_shape(const PlaneGArgs& a, dim3 grid, hipStream_t st) {
 
 int s2p_conv_planeg_launch(PlaneGArgs& a, int groups, hipStream_t st) {
   a.nco = a.Cout / 64;
+  a.img_xcd = (a.N % 8 == 0 && a.nbands > 1 && !S2P_DIAG_SWITCH(15)) ? 1 : 0;      // all bands of an image on one XCD (see the kernel)
   if (a.gb) S2P_FAIL(-1, "conv_planeg: gamma / beta maps are not instantiated for this kernel family");
   if (a.nbands > 1 && a.y2) S2P_FAIL(-1, "conv_planeg: the fused norm needs the whole plane in one workgroup");
   dim3 grid(a.N * a.nbands * a.nco, groups);

@@ -12,6 +12,7 @@ struct HeadArgs {
   const __bf16* x; const __bf16* dy; float* dw; float* db; float* part;
   int N, H, W, Cin, x_pitch, Ho, Wo, y_pitch, KH, KW, pad;
   int cin_real, nchunk, rpb, npix, iters, G;
+  int wpi;                          // streaming form: workgroups per image
 };
 
 template <int KH_, int KW_>        // compile-time kernel size (4x4 for the PatchGAN heads; 0 = run-time, up to 16 taps)
@@ -70,6 +71,75 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const HeadArgs a) {
         part[t * a.Cin + c] = s;
       }
     }
+  }
+}
+
+// Streaming form (round 5; Cin = 512, 4x4).  The kernel above keeps ONE 16-byte load in flight per thread (128 accumulators: one
+// wave per SIMD), 8 KB per CU -- 0.8 TB/s on a 22-MB activation.  Here the activation reaches the thread through LDS-DMA instead:
+// a wave owns every fourth pixel of its workgroup's range, a pixel's 512 channels are ONE 1-KB DMA piece (lane l = channels
+// 8 l .. 8 l + 7), and the wave keeps R = 16 pieces in flight in a private ring (no VGPRs, no barrier: each lane reads back the 16
+// bytes it fetched itself, behind a counted vmcnt).  The logit-gradient map of the image sits in LDS (fp32); a workgroup is a
+// contiguous pixel range of one image, folds its four waves in wave order and stores one partial.  Same partial / reduce scheme.
+template <int R>
+__global__ __launch_bounds__(256, 2) void head_wgrad_stream_kernel(const HeadArgs a) {
+  constexpr int T = 16, KW = 4;
+  __shared__ __attribute__((aligned(1024))) char ring[4 * R * 1024];
+  __shared__ float hmap[400];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = blockIdx.x / a.wpi, part_i = blockIdx.x - n * a.wpi;
+  const int HW = a.H * a.W, nmap = a.Ho * a.Wo;
+  const int per = (HW + a.wpi - 1) / a.wpi, p0 = part_i * per, p1 = p0 + per < HW ? p0 + per : HW;
+  for (int i = tid; i < nmap; i += 256) hmap[i] = (float)a.dy[((size_t)n * nmap + i) * a.y_pitch];
+  __syncthreads();
+  const i32x4 rs = s2p_make_rsrc(a.x + (size_t)n * HW * a.x_pitch, (unsigned)HW * (unsigned)a.x_pitch * 2u);
+  const unsigned ring_lds = __builtin_amdgcn_readfirstlane(s2p_lds_addr(ring)) + (unsigned)wave * (R * 1024);
+  const int npx = p1 - p0 - wave > 0 ? (p1 - p0 - wave + 3) >> 2 : 0;      // pixels p0 + wave + 4 i of this wave
+  auto issue = [&](int i) {                                      // (beyond the range: an out-of-range offset, zeros, same count)
+    const int p = p0 + wave + 4 * i;
+    s2p_dma16(rs, ring_lds + (unsigned)((i % R) * 1024), i < npx ? p * a.x_pitch * 2 + lane * 16 : (int)0x80000000);
+  };
+#pragma unroll
+  for (int i = 0; i < R; ++i) issue(i);
+  float acc[T][8];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
+  for (int i = 0; i < npx; ++i) {
+    S2P_WAIT_VMCNT(R - 1);                                       // the oldest piece (pixel i) has landed
+    Chunk<__bf16> xv;
+    xv.raw = *(const u32x4*)(ring + (wave * R + (i % R)) * 1024 + lane * 16);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // ... and is in registers before its slot is refilled
+    issue(i + R);
+    const int p = p0 + wave + 4 * i, iy = p / a.W, ix = p - iy * a.W;
+    float d[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int ky = t / KW, kx = t - ky * KW;
+      const int oy = iy + a.pad - ky, ox = ix + a.pad - kx;
+      const bool ok = oy >= 0 && oy < a.Ho && ox >= 0 && ox < a.Wo;
+      d[t] = ok ? hmap[oy * a.Wo + ox] : 0.f;
+    }
+    float xf[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xf[e] = xv.get(e);
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[t][e] = __builtin_fmaf(d[t], xf[e], acc[t][e]);
+  }
+  S2P_WAIT_VMCNT(0);
+  __syncthreads();                                               // every ring is quiet: it becomes the fold area [4 waves][512]
+  float* red = (float*)ring;
+  float* part = a.part + (size_t)blockIdx.x * T * a.Cin;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    if (t) __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[wave * 512 + lane * 8 + e] = acc[t][e];
+    __syncthreads();
+    for (int c = tid; c < 512; c += 256) part[t * a.Cin + c] = ((red[c] + red[512 + c]) + red[1024 + c]) + red[1536 + c];
   }
 }
 
@@ -133,7 +203,18 @@ bool s2p_head_wgrad_supported(const s2p_conv_desc* d, int cin_real, int cout_rea
   return true;
 }
 
+// streaming form: Cin = 512, 4x4, the logit map of an image fits the LDS table; workgroups per image so that ~512 run
+static int head_stream_wpi(const s2p_conv_desc* d) {
+  if (S2P_DIAG_SWITCH(12) || d->Cin != 512 || d->KH != 4 || d->KW != 4 || d->Ho * d->Wo > 400 || d->x_pitch % 8) return 0;
+  if ((long long)d->H * d->W * d->x_pitch * 2 >= (1ll << 31)) return 0;
+  int wpi = (512 + d->N - 1) / d->N;
+  const int HW = d->H * d->W;
+  if (wpi > (HW + 7) / 8) wpi = (HW + 7) / 8;                     // at least 8 pixels per workgroup
+  return wpi < 1 ? 1 : wpi;
+}
+
 static int head_groups(const s2p_conv_desc* d) {
+  if (const int wpi = head_stream_wpi(d)) return d->N * wpi;
   const int rpb = 256 / (d->Cin / 8);
   const long long npix = (long long)d->N * d->H * d->W;
   long long g = (npix + (long long)rpb * 8 - 1) / ((long long)rpb * 8);           // >= 8 pixels per thread
@@ -156,7 +237,9 @@ int s2p_head_wgrad(const s2p_conv_desc* d, const void* x, const void* dy, float*
   a.G = head_groups(d);
   a.iters = cdiv(a.npix, (long long)a.G * a.rpb);
   if (!workspace || workspace_bytes < s2p_head_wgrad_workspace(d)) S2P_FAIL(-1, "s2p_head_wgrad: workspace too small");
-  if (a.KH == 4 && a.KW == 4) hipLaunchKernelGGL((head_wgrad_kernel<4, 4>), dim3(a.G), dim3(256), 0, st, a);
+  a.wpi = head_stream_wpi(d);
+  if (a.wpi) hipLaunchKernelGGL((head_wgrad_stream_kernel<16>), dim3(a.G), dim3(256), 0, st, a);
+  else if (a.KH == 4 && a.KW == 4) hipLaunchKernelGGL((head_wgrad_kernel<4, 4>), dim3(a.G), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((head_wgrad_kernel<0, 0>), dim3(a.G), dim3(256), 0, st, a);
   S2P_CHECK_LAUNCH("head_wgrad_kernel");
   const int T = a.KH * a.KW;

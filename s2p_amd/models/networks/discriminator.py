@@ -53,7 +53,7 @@ class NLayerDiscriminator(BaseNetwork):
                 st.add(m.bias, "bias")
             stride = 2 if n < self.n_layers - 1 else 1
             pk = st.pack(f"{prefix}model{n}", [m.weight], [m.bias] if m.bias is not None else None, dtype=dt)
-            self.lay.append(ConvLayer(pk, ConvGeom(cin, self.chans[n], 4, stride, 2)))
+            self.lay.append(ConvLayer(pk, ConvGeom(cin, self.chans[n], 4, stride, 2, net="D")))
             cin = self.chans[n]
 
     def fwd_nhwc(self, x):

@@ -217,6 +217,8 @@ class S2PGenerator(BaseNetwork):
         st.add(self.out.weight, "conv"); st.add(self.out.bias, "bias")
         L["out"] = ConvLayer(st.pack("out", [self.out.weight], [self.out.bias], dtype=dt),
                              ConvGeom(c, 3, 7, 1, 3, reflect=True))
+        for lay in L.values():
+            lay.geom.net = "G"            # (bench.py's per-network aggregates: ops._Prof records it)
         self.lay = L
 
     # ---- explicit forward / backward on NHWC tensors -------------------------------------------------------

@@ -32,7 +32,7 @@ class ConvLayer:
         gm = self.__dict__.setdefault("_gm", {})
         if key not in gm:
             gm[key] = ConvGeom(g.cin, g.cout, g.k, g.stride, g.pad, g.transposed, g.reflect, g.groups, g.output_padding,
-                               x_gstride=g.x_gstride, y_gstride=key)
+                               x_gstride=g.x_gstride, y_gstride=key, net=g.net)
         return gm[key]
 
     def fwd_group_major(self, x, out5):
@@ -66,7 +66,7 @@ class ConvLayer:
         if g.groups > 1 and x.dtype == torch.bfloat16 and g.k == 3 and g.stride == 1 and g.pad == 1 and not g.transposed \
                 and g.groups <= 16 and g.cin % 64 == 0 and g.cout % 64 == 0:
             # grouped 3x3 conv (the 12 gamma/beta heads): one job per group of the batched slab kernel
-            one = ConvGeom(g.cin, g.cout, 3, 1, 1)
+            one = ConvGeom(g.cin, g.cout, 3, 1, 1, net=g.net)
             gw = self.pk.gw.view(g.groups, -1)
             gb = self.pk.gb.view(g.groups, -1) if self.pk.gb is not None else None
             sel = range(g.groups) if groups is None else range(groups[0], groups[1])

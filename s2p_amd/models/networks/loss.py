@@ -71,7 +71,7 @@ class VGG19(BaseNetwork):
             m = getattr(self, name)
             self.store.add(m.weight, "conv"); self.store.add(m.bias, "bias")
             pk = self.store.pack(name, [m.weight], [m.bias], dtype=dt)
-            self.lay[name] = ConvLayer(pk, ConvGeom(cin, cout, 3, 1, 1))
+            self.lay[name] = ConvLayer(pk, ConvGeom(cin, cout, 3, 1, 1, net="VGG"))
 
     def fwd_nhwc(self, x):
         """x: NHWC [B,H,W,ce] (3 real channels).  Returns (tap features, ctx)."""

@@ -34,7 +34,7 @@ class _Prof:
             pix = N * H * W if geom.transposed else N * Ho * Wo
             self.rec = dict(kind=kind, flops=2.0 * pix * geom.cin * geom.cout * geom.k * geom.k * geom.groups,
                             shape=(N, H, W, geom.cin, geom.cout, geom.k, geom.stride, geom.groups, int(geom.transposed)),
-                            dtype=str(dtype))
+                            dtype=str(dtype), net=getattr(geom, "net", ""))
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
@@ -73,7 +73,8 @@ class ConvGeom:
     """Static geometry of one conv layer (F.conv2d / F.conv_transpose2d arguments)."""
 
     def __init__(self, cin, cout, k, stride=1, pad=0, transposed=False, reflect=False, groups=1,
-                 output_padding=0, x_gstride=0, y_gstride=0):
+                 output_padding=0, x_gstride=0, y_gstride=0, net=""):
+        self.net = net              # which network the layer belongs to ("G" / "D" / "VGG": bench.py's per-network aggregates)
         self.cin, self.cout, self.k = cin, cout, k
         self.stride, self.pad = stride, pad
         self.transposed, self.reflect, self.groups = transposed, reflect, groups
@@ -182,6 +183,8 @@ def conv_dgrad_mat(geom, dy, w_bwd, xn, cin_pad, stats, gb, gb_off, gb_st, st_of
     N, H, W, xp = xn.shape
     C = geom.cin
     if cin_pad != C or xp != C:
+        # (a norm's channel count is a multiple of the 16-byte chunk -- the norm kernels require it -- so its tensor is dense; widths such
+        # as --ndf 12 give 24 / 48 / 96 normed channels and take this path unchanged: tests/test_model_gpu.py::test_small_width_discriminator)
         raise ValueError("conv_dgrad_mat: the norm's tensor must be dense in channels (C %d, cin_pad %d, pitch %d)" % (C, cin_pad, xp))
     d = geom.desc(dy.dtype, N, H, W, cin_pad, C, dy.shape[3])
     dxn = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)

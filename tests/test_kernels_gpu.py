@@ -578,10 +578,11 @@ def test_conv_wgrad_split_units_deterministic(hip_device, case):
         assert torch.equal(db, db2)
 
 
-@pytest.mark.parametrize("case", [(512, 4, 13, 13, 5), (128, 4, 8, 7, 3), (64, 3, 9, 9, 2)])
+@pytest.mark.parametrize("case", [(512, 4, 13, 13, 5), (128, 4, 8, 7, 3), (64, 3, 9, 9, 2), (512, 4, 13, 13, 128), (512, 4, 8, 8, 128), (512, 4, 3, 5, 2)])
 def test_conv_wgrad_head(hip_device, case):
     """PatchGAN logit head (Cout = 1, stride 1, pad 2): activation-stationary wgrad (csrc/wgrad_head.hip) behind
-    s2p_conv2d_wgrad_batched, against float64 autograd; accumulates into dw / db; bitwise reproducible."""
+    s2p_conv2d_wgrad_batched, against float64 autograd; accumulates into dw / db; bitwise reproducible.  Cin = 512 with 4x4 taps
+    runs the streaming form (the activation through per-wave LDS-DMA rings), incl. the production batch of both scales."""
     cin, k, H, W, N = case
     dev = hip_device
     g = torch.Generator().manual_seed(cin + k)

@@ -448,6 +448,36 @@ def test_loss_weights_reach_the_gradients(hip_device, tmp_path):
     check_grads(grad_errors(dict(model.netD.named_parameters()), pd64), 1e-5, "weighted D losses")
 
 
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-5), ("bf16", 3e-2)])
+def test_small_width_discriminator(hip_device, tmp_path, precision, tol):
+    """A PatchGAN whose widths are not multiples of 64 nor of the bf16 chunk (--ndf 12: 12 / 24 / 48 / 96 channels; the first,
+    un-normed layer is padded to a 16-channel pitch in bf16): D forward + backward against the float64 oracle with the branches the
+    HIP step took (the discriminator backward goes through s2p_conv2d_dgrad_mat, which takes channel-dense norm tensors)."""
+    opt = TrainOptions().parse(["--env_type", "cheetah", "--batchSize", "2", "--precision", precision, "--gpu_ids", "0",
+                                "--checkpoints_dir", str(tmp_path), "--ndf", "12"], quiet=True)
+    model = Pix2PixModel(opt)
+    spec = O.Spec(state_dim=opt.state_dim, ndf=12)
+    pg = randomize(O.init_params(O.generator_param_shapes(spec), 1), 11, 1.0)
+    pd = randomize(O.init_params(O.discriminator_param_shapes(spec), 2), 12, 1.0)
+    model.netG.load_state_dict(pg)
+    model.netD.load_state_dict(pd)
+    prev, state, real = make_inputs(2, 84, 84, 17, seed=21)
+    data = dict(prev_image=prev, state=state, image=real)
+    model.netD.store.zero_grad()
+    d_losses = model(data, mode="discriminator")
+    dnode = d_losses["D_Fake"].grad_fn
+    dmasks = dstep_masks(model.netD, dnode, 2)
+    fake_hip = _nchw(dnode.dctx_f[0][0], 6)[:, 3:6].double()
+    sum(d_losses.values()).mean().backward()
+    torch.cuda.synchronize()
+    pd64 = to64(pd)
+    D64 = O.discriminator_losses(None, pd64, prev.double(), state.double(), real.double(), spec, masks=dmasks, fake=fake_hip)
+    sum(D64.values()).backward()
+    for k in D64:
+        assert abs(float(d_losses[k]) - float(D64[k])) <= max(tol, 1e-4) * max(abs(float(D64[k])), 1e-2), (k, float(d_losses[k]), float(D64[k]))
+    check_grads(grad_errors(dict(model.netD.named_parameters()), pd64), tol, "small-width D step " + precision)
+
+
 def test_dstep_reuses_the_gstep_real_pass(hip_device, tmp_path):
     """netD(prev, real) is computed once per train step: the G step's pass (feature matching) is handed to the D step
     through model._dreal_cache (same inputs, netD not updated in between -- the reference recomputes it).  The D gradients
