@@ -427,13 +427,43 @@ struct Thin4Args {
   int N, Ho, Wo, Hp, Wp, Cout, y_pitch, act, w_row, w_tap, flip;      // w[(co * w_row + tap * w_tap + ch)]: forward [Cout][49][8], dgrad use [Cin][49][cout_pad]
   float slope;
   int M, tiles, xp_bytes;
+  const u32x4* wfrag;                                                 // weights in MFMA fragment order (pad4_kernel writes them)
 };
-struct Pad4Args { const __bf16* x; __bf16* xp; int N, H, W, x_pitch, Hp, Wp, pad, reflect; };
+struct Pad4Args {
+  const __bf16* x; __bf16* xp; int N, H, W, x_pitch, Hp, Wp, pad, reflect;
+  // the blocks behind the first nb_pad ones pack the weights into fragment order: [co block of 64][2 co tiles][14 steps][64 lanes] x 16 B
+  int nb_pad; const __bf16* w; u32x4* wfrag; int Cout, w_row, w_tap, flip, ncb;
+};
 
 // xp[n][yp][xq][0..3] = x[n][yp - pad][xq - pad][0..3] (reflected or zero outside; columns >= W + 2 pad are zero)
+// ... and, in the blocks behind those, the weights in fragment order (round 5): every thin4_fwd workgroup used to gather its 28 KB of
+// fragments from the packed weights with 2-byte loads -- 56 dependent-latency loads per thread in front of the first MFMA of each of
+// the 1 024 workgroups, most of the kernel's 48 us; now one block per 256 fragments does it once and the workgroups copy 16-byte pieces.
 __global__ __launch_bounds__(256) void pad4_kernel(const Pad4Args a) {
+  if ((int)blockIdx.x >= a.nb_pad) {
+    constexpr int NK = 14;
+    const int f = ((int)blockIdx.x - a.nb_pad) * 256 + threadIdx.x;
+    if (f >= a.ncb * 2 * NK * 64) return;
+    // A[m = co][k = 8 hh + e] of step (ky, j): tap kx = 4 j + 2 hh + (e >> 2), channel e & 3
+    const int ln = f & 63, s = (f >> 6) % NK, ct = (f / (64 * NK)) & 1, cb = f / (2 * 64 * NK);
+    const int co = cb * 64 + ct * 32 + (ln & 31), hh = ln >> 5, ky = s >> 1, j = s & 1;
+    unsigned short e8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int kx = 4 * j + 2 * hh + (e >> 2), ch = e & 3;
+      unsigned short v = 0;
+      if (co < a.Cout && kx < 7) {
+        const int t = ky * 7 + kx, tap = a.flip ? 48 - t : t;
+        v = *(const unsigned short*)(a.w + (size_t)co * a.w_row + (size_t)tap * a.w_tap + ch);
+      }
+      e8[e] = v;
+    }
+    a.wfrag[f] = (u32x4){(unsigned)e8[0] | ((unsigned)e8[1] << 16), (unsigned)e8[2] | ((unsigned)e8[3] << 16),
+                         (unsigned)e8[4] | ((unsigned)e8[5] << 16), (unsigned)e8[6] | ((unsigned)e8[7] << 16)};
+    return;
+  }
   const long long total = (long long)a.N * a.Hp * a.Wp;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)a.nb_pad * 256) {
     const int xq = (int)(i % a.Wp);
     const long long r = i / a.Wp;
     const int yp = (int)(r % a.Hp), n = (int)(r / a.Hp);
@@ -452,31 +482,17 @@ __global__ __launch_bounds__(256) void pad4_kernel(const Pad4Args a) {
   }
 }
 
-__global__ __launch_bounds__(256) void thin4_fwd_kernel(const Thin4Args a) {
+// Round 5: as in thin_cin_fwd_kernel, the next tile's 14 loads are issued before the current tile's MFMAs, and the 32 x 64 output tile
+// goes through a wave-private LDS strip so that every store instruction writes full 128-byte rows (the lane halves' 16-byte pieces,
+// 128 bytes apart, wrote the stem's 58-MB output at 1.3 TB/s: 48 us).
+__global__ __launch_bounds__(512) void thin4_fwd_kernel(const Thin4Args a) {      // 8 waves: one workgroup per CU stages the 28 KB of fragments once
   constexpr int NK = 14;                                              // K steps: (ky, half row): taps kx = 4 j .. 4 j + 3
-  __shared__ __attribute__((aligned(16))) char smem[2 * NK * 1024];   // [2 co tiles][NK] fragments of 64 lanes x 16 B
+  __shared__ __attribute__((aligned(16))) char smem[2 * NK * 1024 + 8 * 32 * CIN_SRS];   // [2 co tiles][NK] fragments of 64 lanes x 16 B + a strip per wave
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int co_base = blockIdx.y * 64;
-  // weights -> fragment order: A[m = co][k = 8 hh + e] of step (ky, j): tap kx = 4 j + 2 hh + (e >> 2), channel e & 3
-  for (int f = tid; f < 2 * NK * 64; f += 256) {
-    const int ln = f & 63, s = (f >> 6) % NK, ct = f / (64 * NK);
-    const int co = co_base + ct * 32 + (ln & 31), hh = ln >> 5, ky = s >> 1, j = s & 1;
-    unsigned short e8[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int kx = 4 * j + 2 * hh + (e >> 2), ch = e & 3;
-      unsigned short v = 0;
-      if (co < a.Cout && kx < 7) {
-        const int t = ky * 7 + kx, tap = a.flip ? 48 - t : t;
-        v = *(const unsigned short*)(a.w + (size_t)co * a.w_row + (size_t)tap * a.w_tap + ch);
-      }
-      e8[e] = v;
-    }
-    u32x4 o = {(unsigned)e8[0] | ((unsigned)e8[1] << 16), (unsigned)e8[2] | ((unsigned)e8[3] << 16),
-               (unsigned)e8[4] | ((unsigned)e8[5] << 16), (unsigned)e8[6] | ((unsigned)e8[7] << 16)};
-    *(u32x4*)(smem + (size_t)f * 16) = o;
-  }
+  // this 64-channel block's weight fragments (pad4_kernel packed them): [2 co tiles][NK][64 lanes] x 16 B
+  for (int f = tid; f < 2 * NK * 64; f += 512) *(u32x4*)(smem + (size_t)f * 16) = a.wfrag[(size_t)blockIdx.y * (2 * NK * 64) + f];
   __syncthreads();
   const int nl = lane & 31, h = lane >> 5;
   __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.xp, 0, a.xp_bytes, 0x00020000);
@@ -491,17 +507,23 @@ __global__ __launch_bounds__(256) void thin4_fwd_kernel(const Thin4Args a) {
       const int co = co_base + ct * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
       bb[ct][i] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
     }
-  for (int tile = blockIdx.x * 4 + wave; tile < a.tiles; tile += gridDim.x * 4) {
+  auto issue_tile = [&](int tile, u32x4 (&bq)[NK]) {
     const int m = tile * 32 + nl;
-    const bool mok = m < a.M;
-    const int mm = mok ? m : 0;
+    const int mm = m < a.M ? m : 0;
     const int n = mm / HoWo, rr = mm - n * HoWo, oy = rr / a.Wo, ox = rr - oy * a.Wo;
     // byte offset of (row oy + ky, column ox + 2 h): + ky * Wp * 8, + j * 32
     const unsigned base = (unsigned)((((size_t)n * a.Hp + oy) * a.Wp + ox + 2 * h) * 8);
-    u32x4 bq[NK];
 #pragma unroll
     for (int s = 0; s < NK; ++s)
       bq[s] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(base + (unsigned)((s >> 1) * a.Wp * 8 + (s & 1) * 32)), 0, 0));
+  };
+  const int tstride = gridDim.x * 8;
+  int tile = blockIdx.x * 8 + wave;
+  u32x4 cur[NK], nxt[NK];
+  if (tile < a.tiles) issue_tile(tile, cur);
+  for (; tile < a.tiles; tile += tstride) {
+    const bool more = tile + tstride < a.tiles;                  // wave-uniform
+    if (more) issue_tile(tile + tstride, nxt);
     const char* wf = smem;
     asm volatile("" : "+v"(wf));                         // opaque per tile: the fragment reads stay in the loop
     f32x16 acc[2];
@@ -511,7 +533,7 @@ __global__ __launch_bounds__(256) void thin4_fwd_kernel(const Thin4Args a) {
       for (int e = 0; e < 16; ++e) acc[ct][e] = 0.f;
 #pragma unroll
     for (int s = 0; s < NK; ++s) {
-      const bf16x8 bf = __builtin_bit_cast(bf16x8, bq[s]);
+      const bf16x8 bf = __builtin_bit_cast(bf16x8, cur[s]);
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
         const bf16x8 af = *(const bf16x8*)(wf + ((size_t)(ct * NK + s) * 64 + lane) * 16);
@@ -520,33 +542,40 @@ __global__ __launch_bounds__(256) void thin4_fwd_kernel(const Thin4Args a) {
     }
     // bias + activation, pack to bf16: pk[ct][q] = channels co_base + 32 ct + 8 q + 4 h + (0..3) of this lane's pixel
     u32x2 pk[2][4];
+    auto pack = [&](auto f) {                               // (the activation is chosen by ONE uniform branch per tile: as a select the
+#pragma unroll                                              //  compiler evaluated tanhf for all 32 outputs of every lane, used or not)
+      for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+        for (int q = 0; q < 4; ++q) {
+          float v[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float t = acc[ct][4 * q + e] + bb[ct][4 * q + e];
-          v[e] = tanh_act ? tanhf(t) : (t > 0.f ? t : t * ns);
+          for (int e = 0; e < 4; ++e) v[e] = f(acc[ct][4 * q + e] + bb[ct][4 * q + e]);
+          const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+          pk[ct][q] = __builtin_bit_cast(u32x2, o);
         }
-        const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-        pk[ct][q] = __builtin_bit_cast(u32x2, o);
-      }
-    // half 0 stores the chunks q = 0, 1 (it needs the partner's 8 bytes of those), half 1 the chunks q = 2, 3
-    __bf16* yp = a.y + (size_t)m * a.y_pitch;
+    };
+    if (tanh_act) pack([](float t) { return tanhf(t); });
+    else pack([ns](float t) { return t > 0.f ? t : t * ns; });
+    // transpose through the wave's private strip (32 pixel rows of 128 + 16 bytes): 8 lanes per pixel, 8 pixels per store instruction.
+    // DS operations of one wave execute in order: no wait between the passes.
+    {
+      char* strip = smem + 2 * NK * 1024 + wave * (32 * CIN_SRS);
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+      for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const u32x2 give = h ? pk[ct][k] : pk[ct][2 + k];
-        u32x2 got;
-        got[0] = (unsigned)__shfl_xor((int)give[0], 32, 64); got[1] = (unsigned)__shfl_xor((int)give[1], 32, 64);
-        const u32x2 own = h ? pk[ct][2 + k] : pk[ct][k];
-        const u32x4 out = h ? (u32x4){got[0], got[1], own[0], own[1]} : (u32x4){own[0], own[1], got[0], got[1]};
-        const int co0 = co_base + ct * 32 + 8 * (2 * h + k);
-        if (mok && co0 < a.Cout) *(u32x4*)(yp + co0) = out;
+        for (int q = 0; q < 4; ++q) *(u32x2*)(strip + nl * CIN_SRS + (32 * ct + 8 * q + 4 * h) * 2) = pk[ct][q];
+      __builtin_amdgcn_wave_barrier();
+      const int m0 = tile * 32, ch = lane & 7;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = (lane >> 3) + 8 * r;
+        const u32x4 out = *(const u32x4*)(strip + row * CIN_SRS + ch * 16);
+        if (m0 + row < a.M && co_base + ch * 8 < a.Cout) *(u32x4*)(a.y + (size_t)(m0 + row) * a.y_pitch + co_base + ch * 8) = out;
       }
+      __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int s = 0; s < NK; ++s) cur[s] = nxt[s];
   }
 }
 
@@ -560,20 +589,25 @@ bool s2p_thin4_fwd_applicable(const s2p_conv_desc* d, int act, int epi) {
   if (d->reflect && (d->H < 4 || d->W < 4)) return false;
   return (long long)d->N * (d->H + 6) * (d->W + 8) * 8 < (1ll << 31) && (long long)d->N * d->H * d->W < (1ll << 31) - 64;
 }
-size_t s2p_thin4_fwd_ws_bytes(const s2p_conv_desc* d) { return (size_t)d->N * (d->H + 6) * (d->W + 8) * 8; }
+static size_t thin4_frag_bytes(int cout) { return (size_t)cdiv(cout, 64) * 2 * 14 * 1024; }
+size_t s2p_thin4_fwd_ws_bytes(const s2p_conv_desc* d) { return (size_t)d->N * (d->H + 6) * (d->W + 8) * 8 + 16 + thin4_frag_bytes(d->Cout); }
 
-static int thin4_launch(Thin4Args& a, const Pad4Args& p, hipStream_t st) {
+static int thin4_launch(Thin4Args& a, Pad4Args& p, hipStream_t st) {
   const long long total = (long long)p.N * p.Hp * p.Wp;
   int pb = (int)((total + 255) / 256); if (pb > 4096) pb = 4096;
-  hipLaunchKernelGGL(pad4_kernel, dim3(pb), dim3(256), 0, st, p);
+  const int ncb = cdiv(a.Cout, 64);
+  // the padded copy is followed (16-byte aligned: total * 8 bytes) by the weight fragments
+  p.nb_pad = pb; p.w = a.w; p.wfrag = (u32x4*)((char*)p.xp + (((size_t)total * 8 + 15) & ~(size_t)15));
+  p.Cout = a.Cout; p.w_row = a.w_row; p.w_tap = a.w_tap; p.flip = a.flip; p.ncb = ncb;
+  a.wfrag = p.wfrag;
+  hipLaunchKernelGGL(pad4_kernel, dim3(pb + cdiv(ncb * 2 * 14 * 64, 256)), dim3(256), 0, st, p);
   S2P_CHECK_LAUNCH("pad4_kernel");
   a.M = a.N * a.Ho * a.Wo; a.tiles = cdiv(a.M, 32);
   a.xp_bytes = (int)(total * 8);
-  const int ncb = cdiv(a.Cout, 64);
-  int gx = cdiv(a.tiles, 4);
-  const int cap = 1024 / ncb > 32 ? 1024 / ncb : 32;
+  int gx = cdiv(a.tiles, 8);
+  const int cap = 256 / ncb > 32 ? 256 / ncb : 32;               // one 8-wave workgroup per CU (180 VGPRs: two waves per SIMD)
   if (gx > cap) gx = cap;
-  hipLaunchKernelGGL(thin4_fwd_kernel, dim3(gx, ncb), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(thin4_fwd_kernel, dim3(gx, ncb), dim3(512), 0, st, a);
   S2P_CHECK_LAUNCH("thin4_fwd_kernel");
   return 0;
 }
@@ -601,7 +635,7 @@ bool s2p_thin4_dgrad_applicable(const s2p_conv_desc* d, int cout_pad) {
 }
 size_t s2p_thin4_dgrad_ws_bytes(const s2p_conv_desc* d) {
   const int e = d->reflect ? 6 : 0;
-  return (size_t)d->N * (d->H + e + 6) * (d->W + e + 8) * 8;
+  return (size_t)d->N * (d->H + e + 6) * (d->W + e + 8) * 8 + 16 + thin4_frag_bytes(d->Cin);
 }
 int s2p_thin4_dgrad(const s2p_conv_desc* d, const void* dy, const void* w_bwd, void* dx, int cout_pad, void* ws, size_t ws_bytes, hipStream_t st) {
   if (!ws || ws_bytes < s2p_thin4_dgrad_ws_bytes(d)) S2P_FAIL(-1, "s2p_conv2d_dgrad: this 7x7 thin-output conv needs %zu bytes of workspace (s2p_conv2d_dgrad_workspace)", s2p_thin4_dgrad_ws_bytes(d));
