@@ -760,7 +760,8 @@ __global__ __launch_bounds__(64) void conv_part_reduce_kernel(const GatherArgs a
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float t = v[e][i];
-      const float w = act_generic ? (a.act == S2P_ACT_TANH ? tanhf(t) : t / (1.f + expf(-t))) : (t > 0.f ? t : t * ns);
+      float w = t > 0.f ? t : t * ns;
+      if (act_generic) w = a.act == S2P_ACT_TANH ? tanhf(t) : t / (1.f + expf(-t));      // (a uniform branch: as a select, tanhf AND expf ran for every element)
       c.set(e, w);                                       // rounded to bf16 here, as the fused epilogue does before epi
     }
     const size_t go = (size_t)m * a.y_pitch + co0;        // same grid, stride 1: output pixel index == GEMM pixel index

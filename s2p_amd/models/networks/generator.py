@@ -410,7 +410,9 @@ class S2PGenerator(BaseNetwork):
             actv.record_stream(ws); dgb_all.record_stream(ws)
         hook = self.on_early_grads
         chunked = GB_WGRAD_CHUNKED and hook is not None and ws is not None and WGRAD_CHUNK_BLOCKS > 0 and gb_all.dim() == 5
-        n_buckets = len(self.early_buckets()) if (hook is not None and chunked) else 1
+        if getattr(self, "_n_buckets", None) is None:
+            self._n_buckets = len(self.early_buckets())
+        n_buckets = self._n_buckets if (hook is not None and chunked) else 1
         pending = []              # batches issued on the side stream whose bucket has not been handed to the exchange yet
 
         def gb_wgrad(b_lo, b_hi):             # the gamma/beta heads of the norms of blocks b_lo..b_hi (groups 2 b_lo .. 2 b_hi + 1)
@@ -420,8 +422,15 @@ class S2PGenerator(BaseNetwork):
             """The previous batch ran under the blocks just finished: re-join the side stream and start that bucket's exchange."""
             nonlocal ws
             if hook is not None and chunked and pending:
-                main.wait_stream(ws)
-                hook(pending.pop(0))
+                if stepgraph.capturing_now():
+                    main.wait_stream(ws)                    # a graph segment ends at the hook: the side stream has to re-join first
+                    hook(pending.pop(0))
+                else:
+                    # eager: only the COMMUNICATION stream waits for the batch (an event on the side stream); the dgrad chain of the
+                    # next blocks on the main stream does not stall behind the weight gradients that were meant to run under it
+                    ev = torch.cuda.Event()
+                    ev.record(ws)
+                    hook(pending.pop(0), after=ev)
 
         wjobs = []
         for k, b in enumerate(reversed(range(self.n_blocks))):

@@ -38,9 +38,9 @@ class FlatAdam:
     def state_dict(self):
         return dict(lr=self.param_groups[0]["lr"], **self.net.store.optimizer_state())
 
-    def load_state_dict(self, st):
+    def load_state_dict(self, st, allow_unsigned=False):
         self.param_groups[0]["lr"] = st.get("lr", self.lr)
-        self.net.store.load_optimizer_state(st)
+        self.net.store.load_optimizer_state(st, allow_unsigned=allow_unsigned)
 
 
 class Pix2PixModel(nn.Module):
@@ -123,8 +123,9 @@ class Pix2PixModel(nn.Module):
         optG = FlatAdam(self.netG, G_lr, (beta1, beta2))
         optD = FlatAdam(self.netD, D_lr, (beta1, beta2))
         if self._resume is not None and "optG" in self._resume:
-            optG.load_state_dict(self._resume["optG"])
-            optD.load_state_dict(self._resume["optD"])
+            unsigned_ok = bool(getattr(opt, "allow_unsigned_optimizer_state", False))
+            optG.load_state_dict(self._resume["optG"], allow_unsigned=unsigned_ok)
+            optD.load_state_dict(self._resume["optD"], allow_unsigned=unsigned_ok)
         self._optimizers = (optG, optD)
         return optG, optD
 

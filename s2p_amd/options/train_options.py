@@ -9,6 +9,9 @@ class TrainOptions(BaseOptions):
         parser.add_argument("--save_latest_freq", type=int, default=5000, help="frequency of saving the latest results")
         parser.add_argument("--save_epoch_freq", type=int, default=10, help="frequency of saving checkpoints at the end of epochs")
         parser.add_argument("--continue_train", action="store_true", help="continue training: load the latest model")
+        parser.add_argument("--allow_unsigned_optimizer_state", action="store_true",
+                            help="--continue_train: also accept optG / optD states written before the flat-layout signature existed "
+                                 "(only if the writing code is known to use this build's parameter order)")
         parser.add_argument("--which_epoch", type=str, default="latest", help="which epoch to load? set to latest to use latest cached model")
         # training
         parser.add_argument("--niter", type=int, default=30, help="# of iter at starting learning rate")

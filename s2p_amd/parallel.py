@@ -55,13 +55,16 @@ class DataParallelGroup:
             s = self._comm = torch.cuda.Stream()
         return s
 
-    def all_reduce_async(self, flat):
-        """Sum `flat` over ranks on the communication stream, after everything issued so far on the current stream.
-        Compute issued later on the current stream runs concurrently; call `join()` before it reads `flat`."""
+    def all_reduce_async(self, flat, after=None):
+        """Sum `flat` over ranks on the communication stream, after everything issued so far on the current stream (and after the
+        event `after`, recorded on another stream that also writes `flat`).  Compute issued later on the current stream runs
+        concurrently; call `join()` before it reads `flat`."""
         if not self.active:
             return
         comm = self.comm_stream()
         comm.wait_stream(torch.cuda.current_stream())
+        if after is not None:
+            comm.wait_event(after)
         with torch.cuda.stream(comm):
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
 

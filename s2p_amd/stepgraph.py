@@ -26,6 +26,12 @@ _ACTIVE = None      # the StepGraph that is capturing right now (one per process
 CAPTURE_PRIORITY = 0   # priority of the stream the step is captured on (-1: above the side streams); measured: see DESIGN.md 6c
 
 
+def capturing_now():
+    """True while a StepGraph of this process is recording a segment (every side stream must re-join before a cut then)."""
+    sg = _ACTIVE
+    return sg is not None and sg.capturing
+
+
 def fork(side, main=None):
     """`side.wait_stream(main)` for a side stream that is about to receive work, with the one rule hipGraph capture imposes
     on this code base checked: while a step is being captured every fork must start from the CAPTURING stream.  A side stream

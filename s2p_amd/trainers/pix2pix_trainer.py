@@ -83,7 +83,7 @@ class Pix2PixTrainer:
         self._cut(act)
         self._eD_waited = True
 
-    def _allreduce_G_tail(self, bucket=None):
+    def _allreduce_G_tail(self, bucket=None, after=None):
         """Hook of the generator's backward: `bucket` (see S2PGenerator.early_buckets) of the flat gradient's early-complete tail is
         final -- start its all-reduce on the communication stream, under the rest of the backward.  bucket None: the whole tail."""
         net = self.pix2pix_model.netG
@@ -97,7 +97,7 @@ class Pix2PixTrainer:
 
         def act():
             for t in parts:
-                self.dp.all_reduce_async(t)
+                self.dp.all_reduce_async(t, after=after)     # `after`: an event of the weight-gradient side stream (eager mode)
         self._cut(act)
 
     def _finish_G_exchange(self):

@@ -191,9 +191,23 @@ def test_flat_param_store_layout_on_cpu():
     sig = st.layout_signature(names)
     a, b = netG.blocks[0].conv_0.weight, netG.blocks[1].conv_0.weight
     swapped = dict(names); swapped[id(a)], swapped[id(b)] = names[id(b)], names[id(a)]
-    assert st.layout_signature(names) == sig and st.layout_signature(swapped) != sig and len(sig) == 16
+    assert st.layout_signature(names) == sig and st.layout_signature(swapped) != sig and sig.startswith("v2:") and len(sig) == 19
     with pytest.raises(RuntimeError, match="no flat-layout signature"):
         st.load_optimizer_state(dict(step=1, m=torch.zeros(st.numel), v=torch.zeros(st.numel)))
+    # the signature is versioned; a state that carries the round-3 hash of an IDENTICAL layout (offset, numel, shape
+    # only), or the round-4 hash without the prefix, still loads; an unsigned one loads only with the explicit opt-in that
+    # FlatAdam.load_state_dict / `--allow_unsigned_optimizer_state` pass down; a foreign signature is refused
+    st.param_names = names
+    z = dict(step=3, m=torch.zeros(st.numel), v=torch.zeros(st.numel))
+    st.load_optimizer_state(dict(z, layout=st.legacy_layout_signature()))
+    st.load_optimizer_state(dict(z, layout=sig[3:]))
+    st.load_optimizer_state(dict(z, layout=sig))
+    st.load_optimizer_state(dict(z), allow_unsigned=True)
+    assert st.step == 3
+    with pytest.raises(RuntimeError, match="different flat parameter layout"):
+        st.load_optimizer_state(dict(z, layout="v2:0123456789abcdef"))
+    popt = TrainOptions().parse(["--gpu_ids", "0", "--allow_unsigned_optimizer_state"], quiet=True)
+    assert popt.allow_unsigned_optimizer_state and not opt.allow_unsigned_optimizer_state
     # data-parallel exchange buckets: they partition the early-complete tail of the flat gradient, the first (the one the backward
     # completes first) ends at the end of the buffer, and at least 2/3 of the tail is in the buckets before the last one
     bk = netG.early_buckets()
