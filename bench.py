@@ -425,7 +425,9 @@ def main():
                 tensor_mb = args.batch * hq * hq * 256 * 2 / 1e6
                 alg_mb = {0: 2 * tensor_mb, 1: 5 * tensor_mb, 2: 8 * tensor_mb}[mat] + 256 * 2304 * 2 / 1e6
                 for k, v in tj.items():
-                    if k.startswith("conv_plane_kernel<7, 22, 0, %d>" % mat) and ("grid %s " % want_grid) in k and "hbm_read_bytes" in v:
+                    # (template arguments <PB, WP, DIAG, MAT[, GST]>: the staged form of round 5 prints a fifth one)
+                    if (k.startswith("conv_plane_kernel<7, 22, 0, %d>" % mat) or k.startswith("conv_plane_kernel<7, 22, 0, %d," % mat)) \
+                            and ("grid %s " % want_grid) in k and "hbm_read_bytes" in v:
                         traffic = int(v["hbm_read_bytes"] + v["hbm_write_bytes"])          # HBM bytes per launch of the dominant kernel
                         traffic_detail = dict(variant=tvar, hbm_read_mb=round(v["hbm_read_bytes"] / 1e6, 2), hbm_write_mb=round(v["hbm_write_bytes"] / 1e6, 2),
                                        algorithmic_mb=round(alg_mb, 2),

@@ -341,6 +341,33 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
   if constexpr ((DIAG & 128) != 0) ph[2] = __builtin_amdgcn_s_memrealtime();
+  // GST: what the tail still takes through registers -- the seventh row group's gamma | beta chunks and, in the backward form, the norm
+  // input xn -- is requested HERE: the loop's fragment registers are dead, and the loads' (cold) latency runs under the accumulator
+  // exchange and the staging pass instead of in front of the first plane sum
+  constexpr int T_MAXR = BPIX / 64, T_KG0 = GST ? 6 : 0;
+  Chunk<T> pre_g[T_MAXR - T_KG0], pre_b[T_MAXR - T_KG0], pre_x[MAT == 2 ? T_MAXR : 1];
+  if constexpr (GST != 0) {
+    const int ch = tid & 7, r0 = tid >> 3, lc = co_base + ch * 8;
+    const T* gbb = (const T*)a.gb + (size_t)img * HW * a.gb_pitch + lc;
+#pragma unroll
+    for (int k = T_KG0; k < T_MAXR; ++k) {
+      const int row = r0 + 64 * k;
+      pre_g[k - T_KG0].raw = (u32x4){0u, 0u, 0u, 0u}; pre_b[k - T_KG0].raw = pre_g[k - T_KG0].raw;
+      if (row < HW) {
+        pre_g[k - T_KG0].raw = *(const u32x4*)(gbb + (size_t)row * a.gb_pitch);
+        pre_b[k - T_KG0].raw = *(const u32x4*)(gbb + (size_t)row * a.gb_pitch + a.Cout);
+      }
+    }
+    if constexpr (MAT == 2) {
+      const T* xb = (const T*)a.xn + (size_t)img * HW * a.xn_pitch + lc;
+#pragma unroll
+      for (int k = 0; k < T_MAXR; ++k) {
+        const int row = r0 + 64 * k;
+        pre_x[k].raw = (u32x4){0u, 0u, 0u, 0u};
+        if (row < HW) pre_x[k].raw = *(const u32x4*)(xb + (size_t)row * a.xn_pitch);
+      }
+    }
+  }
   if constexpr ((DIAG & 16) != 0) {
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     if (tid == 0 && g == 0) { unsigned long long* o = (unsigned long long*)a.y + (size_t)blockIdx.x * 2; o[0] = c1 - st_c0; o[1] = r1 - st_r0; }
@@ -459,14 +486,18 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
     const int ch = tid & 7, r0 = tid >> 3;
     const T* gbb = a.gb ? (const T*)a.gb + (size_t)img * HW * a.gb_pitch + co_base + ch * 8 : nullptr;
     constexpr int KG0 = GST ? GB_ROWS / 64 : 0;                  // rows r0 + 64 k, k < KG0: gamma | beta are staged in LDS
+    static_assert(!GST || KG0 == T_KG0, "row groups staged in LDS");
     Chunk<T> xv[MAXR], gv[MAXR - KG0], bv[MAXR - KG0];
 #pragma unroll
     for (int k = KG0; k < MAXR; ++k) {                           // gamma / beta first: their latency runs under the rest
       const int row = r0 + 64 * k;
-      gv[k - KG0].raw = (u32x4){0u, 0u, 0u, 0u}; bv[k - KG0].raw = gv[k - KG0].raw;
-      if (gbb && row < HW) {
-        gv[k - KG0].raw = *(const u32x4*)(gbb + (size_t)row * a.gb_pitch);
-        bv[k - KG0].raw = *(const u32x4*)(gbb + (size_t)row * a.gb_pitch + a.Cout);
+      if constexpr (GST != 0) { gv[k - KG0] = pre_g[k - KG0]; bv[k - KG0] = pre_b[k - KG0]; }     // (requested behind the loop)
+      else {
+        gv[k - KG0].raw = (u32x4){0u, 0u, 0u, 0u}; bv[k - KG0].raw = gv[k - KG0].raw;
+        if (gbb && row < HW) {
+          gv[k - KG0].raw = *(const u32x4*)(gbb + (size_t)row * a.gb_pitch);
+          bv[k - KG0].raw = *(const u32x4*)(gbb + (size_t)row * a.gb_pitch + a.Cout);
+        }
       }
     }
     // GST: LDS address of this thread's gamma chunk of row r0 (beta: ^ 128); row r0 + 64 k is 64 rows = 16 KB further (r0 + 64 k
@@ -579,7 +610,11 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
       const int row = r0 + 64 * k;
       xv[k].raw = (u32x4){0u, 0u, 0u, 0u}; dv[k].raw = xv[k].raw;
       if (k >= KG0) { gv[k < KG0 ? 0 : k - KG0].raw = xv[k].raw; bv[k < KG0 ? 0 : k - KG0].raw = xv[k].raw; }
-      if (row < HW) {
+      if constexpr (GST != 0) {                                  // xn and the seventh row group's gamma | beta: requested behind the loop
+        xv[k] = pre_x[k];
+        if (k >= KG0) { gv[k < KG0 ? 0 : k - KG0] = pre_g[k < KG0 ? 0 : k - KG0]; bv[k < KG0 ? 0 : k - KG0] = pre_b[k < KG0 ? 0 : k - KG0]; }
+        if (row < HW) dv[k].raw = *(const u32x4*)srow(row, ch);
+      } else if (row < HW) {
         xv[k].raw = *(const u32x4*)(xb + (size_t)row * a.xn_pitch);
         if (k >= KG0 && gbb) { gv[k < KG0 ? 0 : k - KG0].raw = *(const u32x4*)(gbb + (size_t)row * a.gb_pitch); bv[k < KG0 ? 0 : k - KG0].raw = *(const u32x4*)(gbb + (size_t)row * a.gb_pitch + a.Cout); }
         dv[k].raw = *(const u32x4*)srow(row, ch);                // rows beyond HW stay zero: they add nothing to the sums
