@@ -345,7 +345,7 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
   // input xn -- is requested HERE: the loop's fragment registers are dead, and the loads' (cold) latency runs under the accumulator
   // exchange and the staging pass instead of in front of the first plane sum
   constexpr int T_MAXR = BPIX / 64, T_KG0 = GST ? 6 : 0;
-  Chunk<T> pre_g[T_MAXR - T_KG0], pre_b[T_MAXR - T_KG0], pre_x[MAT == 2 ? T_MAXR : 1];
+  Chunk<T> pre_g[T_MAXR - T_KG0], pre_b[T_MAXR - T_KG0], pre_x[MAT == 2 ? T_MAXR : 1], pre_a[MAT == 1 ? T_MAXR : 1];
   if constexpr (GST != 0) {
     const int ch = tid & 7, r0 = tid >> 3, lc = co_base + ch * 8;
     const T* gbb = (const T*)a.gb + (size_t)img * HW * a.gb_pitch + lc;
@@ -356,6 +356,17 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
       if (row < HW) {
         pre_g[k - T_KG0].raw = *(const u32x4*)(gbb + (size_t)row * a.gb_pitch);
         pre_b[k - T_KG0].raw = *(const u32x4*)(gbb + (size_t)row * a.gb_pitch + a.Cout);
+      }
+    }
+    if constexpr (MAT == 1) {                                  // ... and the residual / producer tensor of the conv's own epilogue (conv_1 + skip)
+      if (a.epi != S2P_EPI_STORE) {
+        const T* ab = (const T*)a.aux + (size_t)g * a.y_gstride + (size_t)img * HW * a.y_pitch + lc;
+#pragma unroll
+        for (int k = 0; k < T_MAXR; ++k) {
+          const int row = r0 + 64 * k;
+          pre_a[k].raw = (u32x4){0u, 0u, 0u, 0u};
+          if (row < HW) pre_a[k].raw = *(const u32x4*)(ab + (size_t)row * a.y_pitch);
+        }
       }
     }
     if constexpr (MAT == 2) {
@@ -453,12 +464,12 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
   const bool g_tanh = a.gact == S2P_ACT_TANH;
   const float gneg = a.gact == S2P_ACT_RELU ? 0.f : (a.gact == S2P_ACT_LRELU ? a.gslope : 1.f);
   // one (pixel row, 8-channel chunk) item of the output: staged value (+ residual / producer-activation-gradient epilogue)
-  auto out_chunk = [&](int row, int ch, size_t go) {
+  auto out_chunk = [&](int row, int ch, size_t go, const Chunk<T>* pre = nullptr) {      // pre: aux chunk already in registers
     Chunk<T> c;
     c.raw = *(const u32x4*)srow(row, ch);
     if (a.epi != S2P_EPI_STORE) {
       Chunk<T> x, x2;
-      x.raw = *(const u32x4*)(auxg + go);
+      if (pre) x = *pre; else x.raw = *(const u32x4*)(auxg + go);
       x2.raw = (u32x4){0u, 0u, 0u, 0u};
       if (aux2g) x2.raw = *(const u32x4*)(aux2g + go);
 #pragma unroll
@@ -512,7 +523,7 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
       xv[k].raw = (u32x4){0u, 0u, 0u, 0u};
       if (row < HW) {
         const size_t go = ((size_t)img * HW + row) * a.y_pitch + co_base + ch * 8;
-        xv[k] = out_chunk(row, ch, go);
+        if constexpr (GST != 0) xv[k] = out_chunk(row, ch, go, &pre_a[k]); else xv[k] = out_chunk(row, ch, go);
         *(u32x4*)(yg + go) = xv[k].raw;
       }
     }
