@@ -36,6 +36,10 @@ GB_WGRAD_CHUNKED = True  # with the data-parallel exchange on: the gamma/beta he
 DEC_WGRAD_SIDE = False   # the output / up convs' weight gradients on the weight-gradient stream beside the decoder's backward chain.
                          # Off: same-box A/B 8.980 (side stream) vs 8.942 ms/step -- as in round 3, co-running kernels only trade CUs
 COND_SIDE = True         # backward of the image-conditioning branch on its own stream, concurrent with the encoder backward
+GB_FWD_CHUNKS = 1        # forward: the 12 gamma|beta planes produced in this many launches of 12 / n groups on the conditioning stream, each
+                         # a chunk AHEAD of the ResBlk chain that consumes it (1: one 12-group launch the chain waits
+                         # for).  Same-box A/B (tools/ab_step.py networks.generator.GB_FWD_CHUNKS): 8.783 (1) / 8.773 (2) / 8.772 (3) /
+                         # 8.767 ms (6): nothing -- the chunks that run beside the chain take from it what the earlier start gives
 
 
 class _Linear(nn.Module):
@@ -260,9 +264,17 @@ class S2PGenerator(BaseNetwork):
             seg = ops.resize_nearest(img, hq, wq)
             actv = L["shared"].fwd(seg, act=ACT_RELU)                   # [N,h,w,12*nh]
             gm = GB_GROUP_MAJOR and actv.dtype == torch.bfloat16 and nh % 64 == 0 and (2 * C) % 64 == 0
+            gb_events, gpc = [], 2 * self.n_blocks
             if gm:
-                gb_all = L["gb"].fwd_group_major(actv, torch.empty((2 * self.n_blocks, N, hq, wq, 2 * C), dtype=actv.dtype,
-                                                                   device=actv.device))          # [12,N,h,w,2C]
+                gb_all = torch.empty((2 * self.n_blocks, N, hq, wq, 2 * C), dtype=actv.dtype, device=actv.device)      # [12,N,h,w,2C]
+                nch = GB_FWD_CHUNKS if (cs is not main and GB_FWD_CHUNKS > 1 and (2 * self.n_blocks) % GB_FWD_CHUNKS == 0) else 1
+                gpc = 2 * self.n_blocks // nch                         # groups per chunk
+                for j in range(nch):
+                    L["gb"].fwd_group_major(actv, gb_all, groups=None if nch == 1 else (j * gpc, (j + 1) * gpc))
+                    if nch > 1:
+                        ev = torch.cuda.Event()
+                        ev.record(cs)
+                        gb_events.append(ev)
             else:
                 gb_all = L["gb"].fwd(actv)                              # [N,h,w,12*2C]
         if cs is not main:
@@ -282,12 +294,18 @@ class S2PGenerator(BaseNetwork):
             enc.append((xin, x, s, a))
         # MAT residual blocks
         main.wait_stream(side)                                          # st_all is needed from here on
-        if cs is not main:
+        if cs is not main and not gb_events:
             main.wait_stream(cs)                                        # ... and the gamma/beta maps
         blocks = []
         x = a
         nA = sA = None
+        gb_waited = -1
         for b in range(self.n_blocks):
+            if gb_events:                                               # chunked producer: block b reads the planes 2 b .. 2 b + 2
+                need = min(2 * b + 2, 2 * self.n_blocks - 1) // gpc
+                while gb_waited < need:
+                    gb_waited += 1
+                    main.wait_event(gb_events[gb_waited])
             o0, o1 = (2 * b) * 2 * C, (2 * b + 1) * 2 * C
             G0, G1 = self._gb_plane(gb_all, 2 * b), self._gb_plane(gb_all, 2 * b + 1)
             if FUSE_NORM_FWD:
@@ -309,6 +327,8 @@ class S2PGenerator(BaseNetwork):
             xn = L[f"b{b}c1"].fwd(nB, aux=x, epi=EPI_ADD)
             blocks.append((x, sA, nA, c0, sB, nB))
             x = xn
+        if gb_events:
+            main.wait_stream(cs)                                        # (the conditioning stream re-joins: a captured segment may end)
         # decoder
         dec = []
         for i in range(self.n_down):

@@ -35,10 +35,22 @@ class ConvLayer:
                                x_gstride=g.x_gstride, y_gstride=key, net=g.net)
         return gm[key]
 
-    def fwd_group_major(self, x, out5):
-        """Grouped conv whose group g writes the whole tensor out5[g] ([groups, N, Ho, Wo, pitch])."""
-        ops.conv_fwd(self._group_major(out5), x, self.pk.w_fwd, self.pk.bias, self.cin_pad(x.dtype), y_pitch=out5.shape[4],
-                     out=out5[0])
+    def fwd_group_major(self, x, out5, groups=None):
+        """Grouped conv whose group g writes the whole tensor out5[g] ([groups, N, Ho, Wo, pitch]).  groups=(g0, g1): only the groups
+        g0 .. g1 - 1 (the generator produces the gamma|beta planes in chunks that run ahead of the ResBlk chain)."""
+        gm = self._group_major(out5)
+        if groups is None:
+            ops.conv_fwd(gm, x, self.pk.w_fwd, self.pk.bias, self.cin_pad(x.dtype), y_pitch=out5.shape[4], out=out5[0])
+            return out5
+        g0, g1 = groups
+        sub = self.__dict__.setdefault("_gm_sub", {})
+        key = (out5.stride(0), g1 - g0)
+        if key not in sub:
+            sub[key] = ConvGeom(gm.cin, gm.cout, gm.k, gm.stride, gm.pad, gm.transposed, gm.reflect, g1 - g0, gm.output_padding,
+                                x_gstride=gm.x_gstride, y_gstride=gm.y_gstride, net=gm.net)
+        bias = self.pk.bias[g0 * gm.cout:g1 * gm.cout] if self.pk.bias is not None else None
+        ops.conv_fwd(sub[key], x, self.pk.w_fwd[g0:g1], bias, self.cin_pad(x.dtype), y_pitch=out5.shape[4], out=out5[g0],
+                     x_off=g0 * gm.x_gstride)
         return out5
 
     def fwd_mat(self, x, gb, gb_off, gb_st, st_off, act, slope, aux=None, epi=EPI_STORE):

@@ -95,8 +95,9 @@ class ConvGeom:
 
 
 def conv_fwd(geom, x, w_fwd, bias, cin_pad, y_pitch=None, act=ACT_NONE, slope=0.2, aux=None, epi=EPI_STORE,
-             out=None):
-    """y = act(conv(x, w) + b) [+ aux]   (F.conv2d / F.conv_transpose2d + bias + activation)"""
+             out=None, x_off=0):
+    """y = act(conv(x, w) + b) [+ aux]   (F.conv2d / F.conv_transpose2d + bias + activation).
+    x_off: first channel of x the conv gathers (a range of the groups of a grouped conv over a wide tensor)."""
     N, H, W, xp = x.shape
     ce = chunk_elems(x.dtype)
     Ho, Wo = geom.out_hw(H, W)
@@ -107,7 +108,7 @@ def conv_fwd(geom, x, w_fwd, bias, cin_pad, y_pitch=None, act=ACT_NONE, slope=0.
     need = lib().s2p_conv2d_fwd_workspace(ctypes.byref(d), epi)        # > 0: small-map launch that splits K over the idle CUs
     ws = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None
     pr = _Prof("fwd", geom, N, H, W, x.dtype)
-    check(lib().s2p_conv2d_fwd_ws(ctypes.byref(d), ptr(x), ptr(w_fwd), ptr(bias), ptr(aux), ptr(y), act, slope, epi,
+    check(lib().s2p_conv2d_fwd_ws(ctypes.byref(d), ptr(x) + x_off * x.element_size(), ptr(w_fwd), ptr(bias), ptr(aux), ptr(y), act, slope, epi,
                                   ptr(ws), need, stream()), "s2p_conv2d_fwd")
     pr.done()
     return y
