@@ -677,12 +677,17 @@ extern "C" int s2p_in_norm_fwd(int dtype, const void* x, int N, int HW, int C, i
   const bool simple_act = act == S2P_ACT_NONE || act == S2P_ACT_RELU || act == S2P_ACT_LRELU;   // tanh / swish: two-kernel path
   if (dtype == S2P_BF16 && HW > maxhw && simple_act && !gb_img && S2P_DIAG_SWITCH(9) != 1 && !s2p_env_set("S2P_NO_FUSED_NORM")) {
     // large planes, plain InstanceNorm: the register-resident form (see in_fused_fwd_kernel, MP)
-    const int cs = (HW <= 28 * 64 && C % 64 == 0) ? 64 : ((HW <= 28 * 256 && C % 16 == 0) ? 16 : 0);
+    // planes of <= 1792 pixels: 64-channel slabs at 28 chunks per thread, or -- when those are fewer workgroups than CUs (42x42 x 128 at
+    // N 64: 128) -- 32-channel slabs at 14 chunks (twice the workgroups, 56 VGPRs of payload: round 4 measured 16.9 vs 21.3 us on that
+    // plane and rejected the half slabs only because the SAME switch also halved the 84x84 planes' slabs, 51 vs 36 us)
+    int cs = (HW <= 28 * 64 && C % 64 == 0) ? 64 : ((HW <= 28 * 256 && C % 16 == 0) ? 16 : 0);
+    if (cs == 64 && HW <= 14 * 128 && C % 32 == 0 && N * (C / 64) < 256 && !S2P_DIAG_SWITCH(11)) cs = 32;
     if (cs && N * (C / cs) >= 64) {        // (a handful of workgroups: the two-kernel path spreads over more CUs)
       NormArgs a{}; a.x = x; a.stats = stats; a.gbst = gb_st; a.y = y;
       a.N = N; a.HW = HW; a.C = C; a.x_pitch = pitch; a.gbst_pitch = gb_st_pitch; a.y_pitch = y_pitch; a.act = act; a.slope = slope; a.eps = eps;
       const dim3 lg(N, C / cs);
       if (cs == 64) hipLaunchKernelGGL((in_fused_fwd_kernel<__bf16, 64, 512, false, 28>), lg, dim3(512), 0, (hipStream_t)stream, a);
+      else if (cs == 32) hipLaunchKernelGGL((in_fused_fwd_kernel<__bf16, 32, 512, false, 14>), lg, dim3(512), 0, (hipStream_t)stream, a);
       else hipLaunchKernelGGL((in_fused_fwd_kernel<__bf16, 16, 512, false, 28>), lg, dim3(512), 0, (hipStream_t)stream, a);
       S2P_CHECK_LAUNCH("in_fused_fwd_kernel (large planes)");
       return 0;
