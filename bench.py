@@ -108,12 +108,14 @@ def hbm_rows(batch, size, version):
             n, g_ = [x.strip() for x in k.split("|")][:2]
             pmc[(n, g_.replace("grid ", ""))] = v
     joined = []
+    step_bytes = step_us = 0.0
     for r in csv.DictReader(open(summ)):
         gx = [int(x) for x in r["grid"].split("x")]
         v = pmc.get((r["kernel"], str(gx[0]))) or pmc.get((r["kernel"], str(gx[0] * gx[1] * gx[2])))
         if v is None:
             continue
         by, us = v["hbm_read_bytes"] + v["hbm_write_bytes"], float(r["avg_us"])
+        step_bytes += by * float(r["calls_per_step"]); step_us += float(r["us_per_step"])
         joined.append(dict(kernel=r["kernel"][:80], grid=r["grid"], us_per_step=float(r["us_per_step"]), avg_us=us,
                            hbm_read_mb=round(v["hbm_read_bytes"] / 1e6, 2), hbm_write_mb=round(v["hbm_write_bytes"] / 1e6, 2),
                            achieved_gbs=round(by / us / 1e3, 1), frac=round(by / us / 1e3 / HBM_PEAK_GBS, 4),
@@ -133,7 +135,12 @@ def hbm_rows(batch, size, version):
             j = max(m, key=lambda j: j["hbm_read_mb"])
             amp.append(dict(kernel=name, grid=j["grid"], layer=what, hbm_read_mb=j["hbm_read_mb"], input_mb=round(in_mb, 2),
                             read_amplification=round(j["hbm_read_mb"] / in_mb, 2), avg_us=j["avg_us"]))
-    return dict(peak=HBM_PEAK_GBS, unit="GB/s", rows=rows, read_amplification=amp,
+    # the whole step: HBM-side bytes of every profiled kernel x its launches per step -- what the overlapped streams share
+    whole = dict(gb_per_step=round(step_bytes / 1e9, 2), ms_at_peak=round(step_bytes / (HBM_PEAK_GBS * 1e9) * 1e3, 3),
+                 serial_kernel_ms_covered=round(step_us / 1e3, 3),
+                 note="sum over the kernels found in both files of (FETCH_SIZE x 2 + WRITE_SIZE) per launch x launches per step; the "
+                      "counters sit on the L2's fabric side, so Infinity-Cache hits are included")
+    return dict(peak=HBM_PEAK_GBS, unit="GB/s", rows=rows, read_amplification=amp, whole_step=whole,
                 source="%s + %s" % (os.path.relpath(cands[-1], ROOT), os.path.relpath(summ, ROOT)), commit=meta.get("commit"),
                 s2p_version=meta.get("s2p_version"))
 
