@@ -890,10 +890,13 @@ extern "C" __attribute__((visibility("default"))) int s2p_diag_vgpr_canary(int b
 // 8 = no 192-pixel row bands for the short-K layers (VGG conv1_2 / conv2_x take the 448-pixel bands),
 // 9 = no register-resident InstanceNorm forward for the large planes (reduce + apply instead),
 // 13 = the VALU / shuffle form of the PatchGAN logit-head forward instead of the MFMA one,
-// 14 = the stem's weight gradient on the implicit GEMM instead of the row-streaming kernel with exchanged operands
-int s2p_diag_switch[16] = {0};
+// 14 = the stem's weight gradient on the implicit GEMM instead of the row-streaming kernel with exchanged operands,
+// round 5: 7 = no gamma|beta staging under the K loop (conv_plane GST), 10 = sub-pixel phases of the 64-row conv_dma tile in blockIdx.z,
+// 11 = 64-channel slabs for the 42x42 InstanceNorm forward, 12 = the round-2 logit-head weight gradient, 15 = row bands dealt round-robin
+// over the XCDs, 16 = one (not two) workgroups per CU as the K-split target of the 4x4 weight gradients
+int s2p_diag_switch[32] = {0};
 extern "C" __attribute__((visibility("default"))) int s2p_diag_set(int key, int value) {
-  if (key < 0 || key >= 16) return -1;
+  if (key < 0 || key >= 32) return -1;
   s2p_diag_switch[key] = value;
   return 0;
 }

@@ -25,7 +25,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 #include <stdlib.h>
 #define S2P_DIAGV(a) ((a).diag)
 // run-time A/B switches of the diagnostics build (s2p_diag_set, misc.hip): tools/ab_step.py flips them between captures in ONE process
-extern int s2p_diag_switch[16];
+extern int s2p_diag_switch[32];
 #define S2P_DIAG_SWITCH(k) (s2p_diag_switch[k])
 static inline int s2p_env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 static inline int s2p_env_set(const char* name) { return getenv(name) ? 1 : 0; }

@@ -359,7 +359,7 @@ static bool sg_plan(const s2p_conv_desc* d, int cin_real, int cout_real, WgSlabG
   // K splits per class, in proportion to its taps: ~2 workgroups per CU in total
   // K splits: ~2 workgroups per CU in total, the same number for every class (a block costs a class of 4 taps as much as one of
   // 8: these launches are bound by the DMA round trips of a block, not by its MFMAs)
-  const double unit = 2.0 * sg_ncu() / ((double)a.tiles_per_cls * a.ncls);
+  const double unit = (S2P_DIAG_SWITCH(16) ? 1.0 : 2.0) * sg_ncu() / ((double)a.tiles_per_cls * a.ncls);
   int wg = 0, red = 0;
   size_t fl = 0;
   for (int k = 0; k < a.ncls; ++k) {
