@@ -29,7 +29,7 @@ struct PlaneArgs {
   // dL/d(norm output) and is not stored (y unused); y2 = dL/d(xn) + res, dgb / dgbst = d(gamma | beta) of the image map /
   // the state affine; stats is read (the forward's)
   const void* xn; int xn_pitch; void* dgb; int dgb_pitch; float* dgbst; int dgbst_pitch; const void* res; int res_pitch;
-  int nco;                           // set by the launcher: Cout / 64
+  int nco, gxcd;                     // set by the launcher: Cout / 64; grouped launch with (group, image half) units dealt to the XCDs
   int diag;                          // timing ablations (diagnostics build only)
 };
 

@@ -797,11 +797,21 @@ __global__ __launch_bounds__(512) void conv_plane_pair_kernel(const PlaneArgs a)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int set = wave >> 2, wq = wave & 3;
   const int q = lane >> 4, l15 = lane & 15;
-  const int g = blockIdx.y;
+  int g = blockIdx.y;
   int img, cpair;
   {
     const int bid = blockIdx.x, np = a.nco >> 1;
-    if ((a.N & 7) == 0) { const int xcd = bid & 7, k = bid >> 3; cpair = k % np; img = (k / np) * 8 + xcd; }
+    if (a.gxcd) {
+      // grouped launch, GROUPS on XCDs (round 5).  With the group in blockIdx.y every XCD works on the same group at the same time and
+      // fetches that group's weights into its own L2: 8 copies of all the weights per launch (113 MB of the gamma/beta conv's 200 MB of
+      // reads).  Here the launch is cut into (group, half of the images) units, unit u runs on XCD u % 8 (blocks b, b + 8, ... share an
+      // XCD under the observed round-robin placement: speed only), an XCD's units one after the other: 3 groups' weights per XCD
+      // instead of 12, every activation slice still read by exactly one XCD.
+      const int L = blockIdx.y * gridDim.x + bid, xcd = L & 7, j = L >> 3;
+      const int per_unit = (a.N >> 1) * np;
+      const int u = xcd + 8 * (j / per_unit), r = j % per_unit;
+      g = u >> 1; cpair = r % np; img = (u & 1) * (a.N >> 1) + r / np;
+    } else if ((a.N & 7) == 0) { const int xcd = bid & 7, k = bid >> 3; cpair = k % np; img = (k / np) * 8 + xcd; }
     else { cpair = bid % np; img = bid / np; }
   }
   const int co_base = (2 * cpair + set) * 64;                   // this wave set's slab
@@ -1019,6 +1029,8 @@ int s2p_conv_plane_launch(PlaneArgs& a, int groups, hipStream_t st) {
   // several tiles per CU and an even slab count: two slabs per workgroup from one resident plane (no accumulator exchange)
   if (!a.y2 && (a.nco & 1) == 0 && (long long)a.N * a.nco * groups > 256 && !s2p_env_set("S2P_NO_PLANE_PAIR")) {
     dim3 gp(a.N * (a.nco / 2), groups);
+    // (group, image half) units on XCDs: 2 * groups units over 8 XCDs, whole units per XCD, the grid's x extent a multiple of 8
+    a.gxcd = (groups > 1 && (2 * groups) % 8 == 0 && a.N % 2 == 0 && gp.x % 8 == 0 && !S2P_DIAG_SWITCH(17)) ? 1 : 0;
     hipLaunchKernelGGL((conv_plane_pair_kernel<7, 22, 0>), gp, dim3(512), 0, st, a);
     S2P_CHECK_LAUNCH("conv_plane_pair_kernel");
     return 0;
