@@ -330,3 +330,48 @@ def test_rccl_sum_reduction_is_free_of_the_hazard_class():
             if fn.endswith(".py"):
                 src = open(os.path.join(dirpath, fn)).read()
                 assert not re.search(r"ReduceOp\.(AVG|PREMUL_SUM)|_make_nccl_premul_sum", src), os.path.join(dirpath, fn)
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("s2p_bench", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_resblk_aggregate_counts_generator_launches_only():
+    """VGG conv3_x has the ResBlk conv's shape (64, 21, 21, 256, 256, 3, 1, 1, 0); the north_star aggregate must not
+    pick it up.  Records carry the network tag of their layer (ops._Prof <- ConvGeom.net); the aggregate filters on it."""
+    b = _load_bench()
+    shp = (64, 21, 21, 256, 256, 3, 1, 1, 0)
+    fl = 2.0 * 64 * 21 * 21 * 256 * 256 * 9
+    recs = [dict(kind="fwd", shape=shp, flops=fl, ms=0.040, net="G") for _ in range(24)]
+    recs += [dict(kind="dgrad", shape=shp, flops=fl, ms=0.045, net="G") for _ in range(12)]
+    with_vgg = recs + [dict(kind="fwd", shape=shp, flops=fl, ms=0.032, net="VGG") for _ in range(6)] + \
+        [dict(kind="dgrad", shape=shp, flops=fl, ms=0.030, net="VGG") for _ in range(3)]
+    a0, a1 = b.spade_resblk_aggregate(recs, 64, 84), b.spade_resblk_aggregate(with_vgg, 64, 84)
+    assert a0 is not None and a0["gflop"] == a1["gflop"] and a0["ms"] == a1["ms"] and a0["frac"] == a1["frac"]
+    assert abs(a0["gflop"] - (12 + 12) * fl / 1e9) < 0.1           # forward launches count half (the step runs G forward twice)
+    assert "generator launches only" in a0["includes"]
+    from s2p_amd.ops import ConvGeom
+    assert ConvGeom(3, 8, 3).net == "" and ConvGeom(3, 8, 3, net="D").net == "D"
+
+
+def test_bench_hbm_rows_from_the_committed_profiles():
+    """`roofline.hbm_rows` is built from the latest profiles/round*_pmc_traffic.json + the serial kernel summary of
+    the same round; it refuses files measured on another library version (bench.py then reports null)."""
+    import glob, json
+    b = _load_bench()
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_traffic.json")))
+    assert cands, "no PMC evidence committed"
+    ver = json.load(open(cands[-1]))["_meta"]["s2p_version"]
+    h = b.hbm_rows(64, 84, ver)
+    assert h["peak"] == 8000.0 and h["unit"] == "GB/s" and len(h["rows"]) == 3
+    for r in h["rows"]:
+        assert 0.0 < r["frac"] < 1.0 and r["mfma_busy_share"] < 0.02 and r["achieved_gbs"] == pytest.approx(
+            (r["hbm_read_mb"] + r["hbm_write_mb"]) / r["avg_us"] * 1e3, rel=1e-2)
+    assert 5.0 < h["whole_step"]["gb_per_step"] < 60.0 and h["whole_step"]["ms_at_peak"] == pytest.approx(h["whole_step"]["gb_per_step"] / 8.0, rel=1e-2)
+    assert all(a["read_amplification"] >= 0.9 for a in h["read_amplification"])
+    with pytest.raises(RuntimeError, match="library version"):
+        b.hbm_rows(64, 84, ver + 1000)
