@@ -54,6 +54,22 @@ __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
 }
 
+// m / d and the remainder for 0 <= m < 2^31, d > 0, from a double reciprocal and one correction step each way (the estimate m * (1/d)
+// is within 2^-50 relative of the quotient, so its floor is off by at most one).  An integer division is ~40 VALU instructions on
+// gfx950; the pixel -> (image, row, column) split of the implicit-GEMM kernels' prologues does up to ten of them per lane (round 5:
+// conv_dma_kernel's prologue was ~1 000 instructions per wave in front of the first DMA, as much VALU time as everything else in a
+// short-K tile).
+__device__ __forceinline__ int divmod_rcp(int m, int d, double rcp, int& rem) {
+  int q = (int)((double)m * rcp);
+  int r = m - q * d;
+  const int lo = r < 0 ? 1 : 0;                       // (selects, not branches)
+  q -= lo; r += lo ? d : 0;
+  const int hi = r >= d ? 1 : 0;
+  q += hi; r -= hi ? d : 0;
+  rem = r;
+  return q;
+}
+
 template <typename T> struct Mma;
 template <> struct Mma<__bf16> { static constexpr int BK = 32; };
 template <> struct Mma<float> { static constexpr int BK = 16; };
@@ -71,6 +87,9 @@ __device__ __forceinline__ void conv_epilogue(const GatherArgs& a, f32x16 (&acc)
   const bool act_generic = (a.act == S2P_ACT_TANH || a.act == S2P_ACT_SWISH);
   const float ns = a.act == S2P_ACT_RELU ? 0.f : (a.act == S2P_ACT_LRELU ? a.slope : 1.f);
   if (bias) {
+    // dword buffer loads: channels past Cout read as zero through the descriptor's range check (round 1 guarded every one of the
+    // 16 loads with a branch: ~170 instructions of a tile whose K loop is 100-400)
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)bias, 0, a.Cout * 4, 0x00020000);
 #pragma unroll
     for (int i = 0; i < TCO; ++i)
 #pragma unroll
@@ -78,7 +97,7 @@ __device__ __forceinline__ void conv_epilogue(const GatherArgs& a, f32x16 (&acc)
         const int co = co_base + wco0 + 32 * i + 8 * q4 + 4 * h;
         float bv[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bv[e] = (co + e < a.Cout) ? bias[co + e] : 0.f;
+        for (int e = 0; e < 4; ++e) bv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brs, co * 4, e * 4, 0));
 #pragma unroll
         for (int j = 0; j < TPIX; ++j)
 #pragma unroll
@@ -205,11 +224,13 @@ __global__ __launch_bounds__(256, 2) void conv_gather_kernel(const GatherArgs a)
 
   if (tid < MAX_TAPS) taps[tid] = a.tap[tid];
   const int QQ = a.Qh * a.Qw;
+  const double rcpQQ = 1.0 / (double)QQ, rcpQw = 1.0 / (double)a.Qw;
   if (tid < BPIX) {
     int m = pix_base + tid;
     int off = -1;
     if (m < a.M) {
-      int n = m / QQ, rr = m - n * QQ, qy = rr / a.Qw, qx = rr - qy * a.Qw;
+      int rr, qx;
+      const int n = divmod_rcp(m, QQ, rcpQQ, rr), qy = divmod_rcp(rr, a.Qw, rcpQw, qx);
       off = ((n * a.Ho + qy * a.ostride + a.oy0) * a.Wo + qx * a.ostride + a.ox0);
     }
     rowoff[tid] = off;
@@ -232,7 +253,8 @@ __global__ __launch_bounds__(256, 2) void conv_gather_kernel(const GatherArgs a)
     int m = pix_base + r0 + 64 * i;
     p_ok[i] = m < a.M;
     int mm = p_ok[i] ? m : 0;
-    int n = mm / QQ, rr = mm - n * QQ, qy = rr / a.Qw, qx = rr - qy * a.Qw;
+    int rr, qx;
+    const int n = divmod_rcp(mm, QQ, rcpQQ, rr), qy = divmod_rcp(rr, a.Qw, rcpQw, qx);
     p_py[i] = qy * a.istride; p_px[i] = qx * a.istride; p_base[i] = n * a.Hi;
   }
   const T* xg = (const T*)a.x + (size_t)g * a.x_gstride;
@@ -381,11 +403,13 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const GatherArgs a) {
   const int co_tile = bid % a.nco_tiles, pix_tile = bid / a.nco_tiles;
   const int co_base = co_tile * BCO, pix_base = pix_tile * BPIX;
   const int QQ = a.Qh * a.Qw;
+  const double rcpQQ = 1.0 / (double)QQ, rcpQw = 1.0 / (double)a.Qw;
   if (tid < BPIX) {
     int m = pix_base + tid;
     int off = -1;
     if (m < a.M) {
-      int n = m / QQ, rr = m - n * QQ, qy = rr / a.Qw, qx = rr - qy * a.Qw;
+      int rr, qx;
+      const int n = divmod_rcp(m, QQ, rcpQQ, rr), qy = divmod_rcp(rr, a.Qw, rcpQw, qx);
       off = ((n * a.Ho + qy * a.ostride + a.oy0) * a.Wo + qx * a.ostride + a.ox0);
     }
     rowoff[tid] = off;
@@ -406,7 +430,8 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const GatherArgs a) {
     unsigned long long mask = 0ull;
     unsigned byte = 0u;
     if (m < a.M) {
-      int n = m / QQ, rr = m - n * QQ, qy = rr / a.Qw, qx = rr - qy * a.Qw;
+      int rr, qx;
+      const int n = divmod_rcp(m, QQ, rcpQQ, rr), qy = divmod_rcp(rr, a.Qw, rcpQw, qx);
       int py = qy * a.istride, px = qx * a.istride;
       byte = (unsigned)(((n * a.Hi + py) * a.Wi + px) * a.x_pitch * 2 + jc * 16);
       for (int t = 0; t < a.T; ++t) {
@@ -568,11 +593,18 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const GatherArgs a) {
   const int co_tile = bid % a.nco_tiles, pix_tile = bid / a.nco_tiles;
   const int co_base = co_tile * BCO, pix_base = pix_tile * BPIX;
   const int QQ = pQh * pQw;
+  const double rcpQQ = 1.0 / (double)QQ, rcpQw = 1.0 / (double)pQw;
+  auto split_pixel = [&](int m, int& n, int& qy, int& qx) {
+    int rr;
+    n = divmod_rcp(m, QQ, rcpQQ, rr);
+    qy = divmod_rcp(rr, pQw, rcpQw, qx);
+  };
   if (tid < BPIX) {
     int m = pix_base + tid;
     int off = -1;
     if (m < pM) {
-      int n = m / QQ, rr = m - n * QQ, qy = rr / pQw, qx = rr - qy * pQw;
+      int n, qy, qx;
+      split_pixel(m, n, qy, qx);
       off = ((n * a.Ho + qy * a.ostride + poy0) * a.Wo + qx * a.ostride + pox0);
     }
     rowoff[tid] = off;
@@ -587,8 +619,10 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const GatherArgs a) {
   // lane -> (row inside the 8-row piece, physical chunk); instruction i of wave w stages rows (4i + w)*8 .. +7
   const int lrow = lane >> 3, pc = lane & 7;
   unsigned w_byte[NIW];
+  // pixel rows: byte offset of (n, py, px, chunk) and the pixel's (py, px); a tap's bounds test is two unsigned compares at issue
+  // time (round 1 kept a 64-bit tap mask per row, built in a loop over the taps here)
   unsigned p_byte[NI - NIW];
-  unsigned long long p_mask[NI - NIW];
+  int p_y[NI - NIW], p_x[NI - NIW];
 #pragma unroll
   for (int i = 0; i < NIW; ++i) {
     int row = (4 * i + wave) * 8 + lrow;
@@ -601,19 +635,15 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const GatherArgs a) {
     int row = (4 * (i + NIW) + wave) * 8 + lrow;      // stage row (>= BCO)
     int c = pc ^ ((row >> 1) & 7);
     int m = pix_base + row - BCO;
-    unsigned long long mask = 0ull;
     unsigned byte = 0u;
+    int py = -0x40000000, px = 0;                     // rows past the end of the problem: no tap is in bounds
     if (m < pM) {
-      int n = m / QQ, rr = m - n * QQ, qy = rr / pQw, qx = rr - qy * pQw;
-      int py = qy * a.istride, px = qx * a.istride;
+      int n, qy, qx;
+      split_pixel(m, n, qy, qx);
+      py = qy * a.istride; px = qx * a.istride;
       byte = (unsigned)(((n * a.Hi + py) * a.Wi + px) * a.x_pitch * 2 + c * 16);
-      for (int t = 0; t < pT; ++t) {
-        int ti = ptap[t];
-        int iy = py + (int)(signed char)(ti & 0xff), ix = px + (int)(signed char)((ti >> 8) & 0xff);
-        if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) mask |= 1ull << t;
-      }
     }
-    p_byte[i] = byte; p_mask[i] = mask;
+    p_byte[i] = byte; p_y[i] = py; p_x[i] = px;
   }
 
   int nk = pKtot / BK;
@@ -639,7 +669,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const GatherArgs a) {
                                                (int)(w_byte[i] == OOB ? OOB : w_byte[i] + (unsigned)woff), 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < NI - NIW; ++i) {
-      bool ok = (p_mask[i] >> tap) & 1ull;
+      bool ok = (unsigned)(p_y[i] + dy) < (unsigned)a.Hi && (unsigned)(p_x[i] + dx) < (unsigned)a.Wi;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(base + (i + NIW) * (32 * RS)), 16,
                                                (int)(ok ? p_byte[i] + (unsigned)toff : OOB), 0, 0, 0);
     }
