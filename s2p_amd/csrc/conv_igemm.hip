@@ -54,22 +54,6 @@ __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
 }
 
-// m / d and the remainder for 0 <= m < 2^31, d > 0, from a double reciprocal and one correction step each way (the estimate m * (1/d)
-// is within 2^-50 relative of the quotient, so its floor is off by at most one).  An integer division is ~40 VALU instructions on
-// gfx950; the pixel -> (image, row, column) split of the implicit-GEMM kernels' prologues does up to ten of them per lane (round 5:
-// conv_dma_kernel's prologue was ~1 000 instructions per wave in front of the first DMA, as much VALU time as everything else in a
-// short-K tile).
-__device__ __forceinline__ int divmod_rcp(int m, int d, double rcp, int& rem) {
-  int q = (int)((double)m * rcp);
-  int r = m - q * d;
-  const int lo = r < 0 ? 1 : 0;                       // (selects, not branches)
-  q -= lo; r += lo ? d : 0;
-  const int hi = r >= d ? 1 : 0;
-  q += hi; r -= hi ? d : 0;
-  rem = r;
-  return q;
-}
-
 template <typename T> struct Mma;
 template <> struct Mma<__bf16> { static constexpr int BK = 32; };
 template <> struct Mma<float> { static constexpr int BK = 16; };
@@ -128,7 +112,7 @@ __device__ __forceinline__ void conv_epilogue(const GatherArgs& a, f32x16 (&acc)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float t = acc[i][j][4 * q4 + e];
-          v[e] = act_generic ? t : (t > 0.f ? t : t * ns);
+          v[e] = act_generic ? t : lrelu_ns(t, ns);
         }
         if constexpr (sizeof(T) == 2) {
           bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
@@ -171,13 +155,14 @@ __device__ __forceinline__ void conv_epilogue(const GatherArgs& a, f32x16 (&acc)
           if (aux2g) x2.set(e, to_f32(aux2g[go + e]));
         }
       }
+      float ov[CE];
 #pragma unroll
       for (int e = 0; e < CE; ++e) {
         float v = c.get(e), xv = x.get(e);
         float f = g_tanh ? 1.f - xv * xv : (xv > 0.f ? 1.f : gneg);
-        v = epi_add ? v + xv : (v + x2.get(e)) * f;
-        c.set(e, v);
+        ov[e] = epi_add ? v + xv : (v + x2.get(e)) * f;
       }
+      c.pack(ov);
     }
     if constexpr (sizeof(T) == 4) {
       if (a.splitk > 1) {
@@ -224,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_kernel(const GatherArgs a)
 
   if (tid < MAX_TAPS) taps[tid] = a.tap[tid];
   const int QQ = a.Qh * a.Qw;
-  const double rcpQQ = 1.0 / (double)QQ, rcpQw = 1.0 / (double)a.Qw;
+  const double rcpQQ = s2p_rcp_f64(QQ), rcpQw = s2p_rcp_f64(a.Qw);
   if (tid < BPIX) {
     int m = pix_base + tid;
     int off = -1;
@@ -403,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const GatherArgs a) {
   const int co_tile = bid % a.nco_tiles, pix_tile = bid / a.nco_tiles;
   const int co_base = co_tile * BCO, pix_base = pix_tile * BPIX;
   const int QQ = a.Qh * a.Qw;
-  const double rcpQQ = 1.0 / (double)QQ, rcpQw = 1.0 / (double)a.Qw;
+  const double rcpQQ = s2p_rcp_f64(QQ), rcpQw = s2p_rcp_f64(a.Qw);
   if (tid < BPIX) {
     int m = pix_base + tid;
     int off = -1;
@@ -593,7 +578,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const GatherArgs a) {
   const int co_tile = bid % a.nco_tiles, pix_tile = bid / a.nco_tiles;
   const int co_base = co_tile * BCO, pix_base = pix_tile * BPIX;
   const int QQ = pQh * pQw;
-  const double rcpQQ = 1.0 / (double)QQ, rcpQw = 1.0 / (double)pQw;
+  const double rcpQQ = s2p_rcp_f64(QQ), rcpQw = s2p_rcp_f64(pQw);
   auto split_pixel = [&](int m, int& n, int& qy, int& qx) {
     int rr;
     n = divmod_rcp(m, QQ, rcpQQ, rr);
@@ -786,14 +771,16 @@ __global__ __launch_bounds__(64) void conv_part_reduce_kernel(const GatherArgs a
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + i;
     if (m >= a.M) break;
-    Chunk<T> c; c.raw = (u32x4){0u, 0u, 0u, 0u};
+    Chunk<T> c;
+    float wv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float t = v[e][i];
-      float w = t > 0.f ? t : t * ns;
+      float w = lrelu_ns(t, ns);
       if (act_generic) w = a.act == S2P_ACT_TANH ? tanhf(t) : t / (1.f + expf(-t));      // (a uniform branch: as a select, tanhf AND expf ran for every element)
-      c.set(e, w);                                       // rounded to bf16 here, as the fused epilogue does before epi
+      wv[e] = w;
     }
+    c.pack(wv);                                          // rounded to bf16 here, as the fused epilogue does before epi
     const size_t go = (size_t)m * a.y_pitch + co0;        // same grid, stride 1: output pixel index == GEMM pixel index
     if (a.epi != S2P_EPI_STORE) {
       Chunk<T> x, x2;
@@ -811,8 +798,9 @@ __global__ __launch_bounds__(64) void conv_part_reduce_kernel(const GatherArgs a
       for (int e = 0; e < 8; ++e) {
         const float xv = x.get(e);
         const float f = g_tanh ? 1.f - xv * xv : (xv > 0.f ? 1.f : gneg);
-        c.set(e, epi_add ? c.get(e) + xv : (c.get(e) + x2.get(e)) * f);
+        wv[e] = epi_add ? c.get(e) + xv : (c.get(e) + x2.get(e)) * f;
       }
+      c.pack(wv);
     }
     if (full) *(u32x4*)(y + go) = c.raw;
     else for (int e = 0; e < 8; ++e) if (co0 + e < a.Cst) y[go + e] = from_f32<T>(c.get(e));
@@ -1576,6 +1564,8 @@ static int conv_fwd_impl(const s2p_conv_desc* d, const void* x, const void* w_fw
                          void* y, int act, float slope, int epi, const Scratch& sc, void* stream) {
   int rc = check_desc(d, "s2p_conv2d_fwd");
   if (rc) return rc;
+  S2P_CHECK_SLOPE("s2p_conv2d_fwd", act, slope);
+  if (sc.mat) S2P_CHECK_SLOPE("s2p_conv2d_fwd_mat", sc.mat->act, sc.mat->slope);
   if (!sc.plan) {
     if (!x || !w_fwd || !y) S2P_FAIL(-1, "s2p_conv2d_fwd: null pointer");
     if (epi != S2P_EPI_STORE && !aux) S2P_FAIL(-1, "s2p_conv2d_fwd: epi needs aux");

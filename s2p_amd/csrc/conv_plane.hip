@@ -451,7 +451,7 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
     else if (a.act == S2P_ACT_NONE) stage_out([](float v) { return v; });        // (dgrads, gamma/beta conv: the pass is VALU-bound)
     else {
       const float ns = a.act == S2P_ACT_RELU ? 0.f : a.slope;                    // relu / lrelu
-      stage_out([ns](float v) { return v > 0.f ? v : v * ns; });
+      stage_out([ns](float v) { return lrelu_ns(v, ns); });
     }
   };
   if (set == 0) finish(std::integral_constant<int, 0>{}); else finish(std::integral_constant<int, 2>{});
@@ -472,13 +472,14 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
       if (pre) x = *pre; else x.raw = *(const u32x4*)(auxg + go);
       x2.raw = (u32x4){0u, 0u, 0u, 0u};
       if (aux2g) x2.raw = *(const u32x4*)(aux2g + go);
+      float ov[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float v = c.get(e), xv = x.get(e);
         const float f = g_tanh ? 1.f - xv * xv : (xv > 0.f ? 1.f : gneg);
-        v = epi_add ? v + xv : (v + x2.get(e)) * f;
-        c.set(e, v);
+        ov[e] = epi_add ? v + xv : (v + x2.get(e)) * f;
       }
+      c.pack(ov);
     }
     return c;
   };
@@ -517,6 +518,10 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
       const int row = r0 + 64 * k;
       return (row < GB_ROWS_B ? GB_B + row * 256 : (row - GB_ROWS_B) * 256) + ((r0 & 1) << 7) + ch * 16;
     };
+    // The plane stays in registers UNPACKED from here on (56 floats: the accumulators are dead): round 4 kept it packed and paid
+    // three unpack passes; with the centred values kept from the second pass, the maximum form of the activation and paired
+    // bf16 conversions the tail is ~330 VALU instructions per wave shorter (of 1 320)
+    float xf[MAXR][8];
 #pragma unroll
     for (int k = 0; k < MAXR; ++k) {
       const int row = r0 + 64 * k;
@@ -526,6 +531,7 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
         if constexpr (GST != 0) xv[k] = out_chunk(row, ch, go, &pre_a[k]); else xv[k] = out_chunk(row, ch, go);
         *(u32x4*)(yg + go) = xv[k].raw;
       }
+      xv[k].unpack(xf[k]);                                        // rows beyond HW hold zeros
     }
     __syncthreads();                                            // the staging rows are dead: LDS is scratch from here on
     float* red = (float*)(smem + XOFF);                         // [8 waves][64]
@@ -556,17 +562,21 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
     for (int e = 0; e < 8; ++e) {
       sacc[e] = 0.f;
 #pragma unroll
-      for (int k = 0; k < MAXR; ++k) sacc[e] += xv[k].get(e);      // rows beyond HW hold zeros
+      for (int k = 0; k < MAXR; ++k) sacc[e] += xf[k][e];
     }
     plane_sum(sacc, 0);
+    // rows r0 + 64 k with k < KFULL exist in every thread (GST: the host requires HW >= 384): no bounds select on their squares
+    constexpr int KFULL = GST ? 6 : 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       mean[e] = cst[ch * 8 + e] * inv;
       sacc[e] = 0.f;
 #pragma unroll
       for (int k = 0; k < MAXR; ++k) {
-        const float d = xv[k].get(e) - mean[e];
-        sacc[e] += (r0 + 64 * k < HW) ? d * d : 0.f;
+        const float d = xf[k][e] - mean[e];
+        xf[k][e] = d;                                             // the centred value is what the last pass needs
+        if (k < KFULL) sacc[e] = __builtin_fmaf(d, d, sacc[e]);
+        else sacc[e] += (r0 + 64 * k < HW) ? d * d : 0.f;
       }
     }
     plane_sum(sacc, 1);
@@ -594,13 +604,15 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
       Chunk<T> o0, gk, bk;
       if (k < KG0) { const int go = gst_row(k); gk.raw = *(const u32x4*)(smem + go); bk.raw = *(const u32x4*)(smem + (go ^ 128)); }
       else { gk = gv[k < KG0 ? 0 : k - KG0]; bk = bv[k < KG0 ? 0 : k - KG0]; }
+      float ov[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float gg = gs[e] + gk.get(e), bb = bs[e] + bk.get(e);
-        const float xh = (xv[k].get(e) - mean[e]) * rstd[e];
+        const float xh = xf[k][e] * rstd[e];                      // (x - mean) * rstd
         const float yv = __builtin_fmaf(xh, gg, bb);              // (norm.hip: mat_value)
-        o0.set(e, yv > 0.f ? yv : yv * nns);
+        ov[e] = lrelu_ns(yv, nns);
       }
+      o0.pack(ov);
       *(u32x4*)(y2 + (size_t)row * a.y2_pitch) = o0.raw;
     }
   }
@@ -661,10 +673,15 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
     }
     __syncthreads();
     const float gneg = a.n_act == S2P_ACT_RELU ? 0.f : (a.n_act == S2P_ACT_LRELU ? a.n_slope : 1.f);
-    unsigned long long posmask = 0ull;                          // activation branch per (row k, element e): pass 2 reuses pass 1's
-    // ---- pass 1: the four plane sums
-    if constexpr (GST != 0) {
-      // rows outermost (one LDS read of the staged gamma | beta chunk per row); every sum still adds its rows in ascending order
+    // ---- pass 1: the four plane sums.  Rows outermost (one read of the gamma | beta chunk per row); every sum adds its rows in
+    // ascending order.  The normalised input xh and the gradient dy behind the activation stay in registers for pass 2 (112 floats:
+    // the accumulators are dead) -- round 4 recomputed both there from the packed chunks and a 64-bit mask of the activation
+    // branches: 40 VALU instructions per element over the two passes, now ~23
+    float xhf[MAXR][8], dyf[MAXR][8];
+    {
+      float mm[8], rr[8], g1[8], b1[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const int cl = ch * 8 + e; mm[e] = cst[cl]; rr[e] = cst[64 + cl]; g1[e] = cst[128 + cl]; b1[e] = cst[192 + cl]; }
       float q0[8], q1[8], q2[8], q3[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) { q0[e] = 0.f; q1[e] = 0.f; q2[e] = 0.f; q3[e] = 0.f; }
@@ -674,14 +691,13 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
         load_gb(k, gk, bk);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int cl = ch * 8 + e;
-          const float gg = cst[128 + cl] + gk.get(e), bb = cst[192 + cl] + bk.get(e);
-          const float xh = (xv[k].get(e) - cst[cl]) * cst[64 + cl];
+          const float gg = g1[e] + gk.get(e), bb = b1[e] + bk.get(e);
+          const float xh = (xv[k].get(e) - mm[e]) * rr[e];
           const float yv = __builtin_fmaf(xh, gg, bb);          // (norm.hip: mat_value -- the forward's rounding)
-          const bool pos = yv > 0.f;
-          posmask |= pos ? (1ull << (k * 8 + e)) : 0ull;
-          const float dy = dv[k].get(e) * (pos ? 1.f : gneg);
+          const float dvv = dv[k].get(e);
+          const float dy = yv > 0.f ? dvv : dvv * gneg;
           const float dxh = dy * gg;
+          xhf[k][e] = xh; dyf[k][e] = dy;
           q0[e] += dxh; q1[e] += dxh * xh; q2[e] += dy * xh; q3[e] += dy;
         }
       }
@@ -694,28 +710,6 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
         }
         if (lane < 8) { red[(0 * 8 + wave) * 64 + cl] = q0[e]; red[(1 * 8 + wave) * 64 + cl] = q1[e]; red[(2 * 8 + wave) * 64 + cl] = q2[e]; red[(3 * 8 + wave) * 64 + cl] = q3[e]; }
       }
-    } else
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int cl = ch * 8 + e;
-      const float m = cst[cl], r = cst[64 + cl], g1 = cst[128 + cl], b1 = cst[192 + cl];
-      float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
-#pragma unroll
-      for (int k = 0; k < MAXR; ++k) {
-        const float gg = g1 + gv[k].get(e), bb = b1 + bv[k].get(e);
-        const float xh = (xv[k].get(e) - m) * r;
-        const float yv = __builtin_fmaf(xh, gg, bb);            // (norm.hip: mat_value -- the forward's rounding)
-        const bool pos = yv > 0.f;
-        posmask |= pos ? (1ull << (k * 8 + e)) : 0ull;
-        const float dy = dv[k].get(e) * (pos ? 1.f : gneg);
-        const float dxh = dy * gg;
-        q0 += dxh; q1 += dxh * xh; q2 += dy * xh; q3 += dy;
-      }
-#pragma unroll
-      for (int o = 8; o < 64; o <<= 1) {
-        q0 += __shfl_xor(q0, o, 64); q1 += __shfl_xor(q1, o, 64); q2 += __shfl_xor(q2, o, 64); q3 += __shfl_xor(q3, o, 64);
-      }
-      if (lane < 8) { red[(0 * 8 + wave) * 64 + cl] = q0; red[(1 * 8 + wave) * 64 + cl] = q1; red[(2 * 8 + wave) * 64 + cl] = q2; red[(3 * 8 + wave) * 64 + cl] = q3; }
     }
     __syncthreads();
     if (tid < 64) {
@@ -735,28 +729,32 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
     T* dxo = (T*)a.y2 + (size_t)img * HW * a.y2_pitch + lc;
     T* dgo = a.dgb ? (T*)a.dgb + (size_t)img * HW * a.dgb_pitch + lc : nullptr;
     const T* rsb = a.res ? (const T*)a.res + (size_t)img * HW * a.res_pitch + lc : nullptr;
+    float rr2[8], g12[8], s1v[8], s2v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const int cl = ch * 8 + e; rr2[e] = cst[64 + cl]; g12[e] = cst[128 + cl]; s1v[e] = cst[256 + cl]; s2v[e] = cst[320 + cl]; }
 #pragma unroll
     for (int k = 0; k < MAXR; ++k) {
       const int row = r0 + 64 * k;
       if (row >= HW) break;
       Chunk<T> o0, o1, o2, gk, bk;
       load_gb(k, gk, bk);
+      float v0[8], v1[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int cl = ch * 8 + e;
-        const float m = cst[cl], r = cst[64 + cl], gg = cst[128 + cl] + gk.get(e), s1 = cst[256 + cl], s2 = cst[320 + cl];
-        const float xh = (xv[k].get(e) - m) * r;
-        const float dy = dv[k].get(e) * (((posmask >> (k * 8 + e)) & 1ull) ? 1.f : gneg);
+        const float gg = g12[e] + gk.get(e);
+        const float xh = xhf[k][e], dy = dyf[k][e];
         const float dxh = dy * gg;
-        o0.set(e, r * (dxh - s1 - xh * s2));
-        o1.set(e, dy * xh);
-        o2.set(e, dy);
+        v0[e] = rr2[e] * (dxh - s1v[e] - xh * s2v[e]);
+        v1[e] = dy * xh;
       }
       if (rsb) {                                                // skip-connection gradient folded into the store (fp32 add, one rounding)
         Chunk<T> rv; rv.raw = *(const u32x4*)(rsb + (size_t)row * a.res_pitch);
+        // (round 4 rounded dx to bf16 before the add: o0.get(e) + rv.get(e); kept, bit for bit)
+        o0.pack(v0);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o0.set(e, o0.get(e) + rv.get(e));
+        for (int e = 0; e < 8; ++e) v0[e] = o0.get(e) + rv.get(e);
       }
+      o0.pack(v0); o1.pack(v1); o2.pack(dyf[k]);
       *(u32x4*)(dxo + (size_t)row * a.y2_pitch) = o0.raw;
       if (dgo) {
         *(u32x4*)(dgo + (size_t)row * a.dgb_pitch) = o1.raw;
@@ -974,7 +972,7 @@ __global__ __launch_bounds__(512) void conv_plane_pair_kernel(const PlaneArgs a)
     else if (a.act == S2P_ACT_NONE) stage_out([](float v) { return v; });        // (dgrads, gamma/beta conv: the pass is VALU-bound)
     else {
       const float ns = a.act == S2P_ACT_RELU ? 0.f : a.slope;
-      stage_out([ns](float v) { return v > 0.f ? v : v * ns; });
+      stage_out([ns](float v) { return lrelu_ns(v, ns); });
     }
   }
   __syncthreads();
@@ -995,13 +993,14 @@ __global__ __launch_bounds__(512) void conv_plane_pair_kernel(const PlaneArgs a)
         x.raw = *(const u32x4*)(auxg + go);
         x2.raw = (u32x4){0u, 0u, 0u, 0u};
         if (aux2g) x2.raw = *(const u32x4*)(aux2g + go);
+        float ov[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float v = c.get(e), xv = x.get(e);
           const float f = g_tanh ? 1.f - xv * xv : (xv > 0.f ? 1.f : gneg);
-          v = epi_add ? v + xv : (v + x2.get(e)) * f;
-          c.set(e, v);
+          ov[e] = epi_add ? v + xv : (v + x2.get(e)) * f;
         }
+        c.pack(ov);
       }
       *(u32x4*)(yg + go) = c.raw;
     }

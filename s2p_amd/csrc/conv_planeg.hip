@@ -317,7 +317,7 @@ __global__ __launch_bounds__(512, ((PB <= 3 && (TY == 3 || PG_OCC4_ALL)) ? 4 : 2
     else if (a.act == S2P_ACT_NONE) stage_out([](float v) { return v; });
     else {
       const float ns = a.act == S2P_ACT_RELU ? 0.f : a.slope;
-      stage_out([ns](float v) { return v > 0.f ? v : v * ns; });
+      stage_out([ns](float v) { return lrelu_ns(v, ns); });
     }
   };
   if (set == 0) finish(std::integral_constant<int, 0>{}); else finish(std::integral_constant<int, 2>{});
@@ -337,13 +337,14 @@ __global__ __launch_bounds__(512, ((PB <= 3 && (TY == 3 || PG_OCC4_ALL)) ? 4 : 2
       x.raw = *(const u32x4*)(auxg + go);
       x2.raw = (u32x4){0u, 0u, 0u, 0u};
       if (aux2g) x2.raw = *(const u32x4*)(aux2g + go);
+      float ov[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float v = c.get(e), xv = x.get(e);
         const float f = g_tanh ? 1.f - xv * xv : (xv > 0.f ? 1.f : gneg);
-        v = epi_add ? v + xv : (v + x2.get(e)) * f;
-        c.set(e, v);
+        ov[e] = epi_add ? v + xv : (v + x2.get(e)) * f;
       }
+      c.pack(ov);
     }
     return c;
   };
@@ -380,6 +381,10 @@ __global__ __launch_bounds__(512, ((PB <= 3 && (TY == 3 || PG_OCC4_ALL)) ? 4 : 2
         *(u32x4*)(yg + go) = xv[k].raw;
       }
     }
+    // the plane unpacked ONCE, the centred values kept from the second pass for the third (conv_plane.hip, MAT == 1; round 5)
+    float xf[MAXR][8];
+#pragma unroll
+    for (int k = 0; k < MAXR; ++k) xv[k].unpack(xf[k]);
     __syncthreads();                                            // the staging rows are dead: LDS is scratch from here on
     float* red = (float*)smem;                                  // [8 waves][64]
     float* cst = (float*)smem + 8 * 64;                         // [4][64]: plane sum / M2, then 1 + gamma_st, beta_st
@@ -409,7 +414,7 @@ __global__ __launch_bounds__(512, ((PB <= 3 && (TY == 3 || PG_OCC4_ALL)) ? 4 : 2
     for (int e = 0; e < 8; ++e) {
       sacc[e] = 0.f;
 #pragma unroll
-      for (int k = 0; k < MAXR; ++k) sacc[e] += xv[k].get(e);      // rows beyond HW hold zeros
+      for (int k = 0; k < MAXR; ++k) sacc[e] += xf[k][e];          // rows beyond HW hold zeros
     }
     plane_sum(sacc, 0);
 #pragma unroll
@@ -418,7 +423,8 @@ __global__ __launch_bounds__(512, ((PB <= 3 && (TY == 3 || PG_OCC4_ALL)) ? 4 : 2
       sacc[e] = 0.f;
 #pragma unroll
       for (int k = 0; k < MAXR; ++k) {
-        const float d = xv[k].get(e) - mean[e];
+        const float d = xf[k][e] - mean[e];
+        xf[k][e] = d;
         sacc[e] += (r0 + 64 * k < HW) ? d * d : 0.f;
       }
     }
@@ -445,13 +451,15 @@ __global__ __launch_bounds__(512, ((PB <= 3 && (TY == 3 || PG_OCC4_ALL)) ? 4 : 2
       const int row = r0 + 64 * k;
       if (row >= HW) break;
       Chunk<T> o0;
+      float ov[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float gg = gs[e] + (GB ? gv[k].get(e) : 0.f), bb = bs[e] + (GB ? bv[k].get(e) : 0.f);
-        const float xh = (xv[k].get(e) - mean[e]) * rstd[e];
+        const float xh = xf[k][e] * rstd[e];                      // (x - mean) * rstd
         const float yv = __builtin_fmaf(xh, gg, bb);              // (norm.hip: mat_value)
-        o0.set(e, yv > 0.f ? yv : yv * nns);
+        ov[e] = lrelu_ns(yv, nns);
       }
+      o0.pack(ov);
       *(u32x4*)(y2 + (size_t)row * a.y2_pitch) = o0.raw;
     }
   } else {
@@ -494,7 +502,9 @@ __global__ __launch_bounds__(512, ((PB <= 3 && (TY == 3 || PG_OCC4_ALL)) ? 4 : 2
     }
     __syncthreads();
     const float nneg = a.n_act == S2P_ACT_RELU ? 0.f : (a.n_act == S2P_ACT_LRELU ? a.n_slope : 1.f);
-    unsigned long long posmask = 0ull;                          // activation branch per (row k, element e): pass 2 reuses pass 1's
+    // the normalised input xh and the gradient dy behind the activation stay in registers for the output pass (conv_plane.hip,
+    // MAT == 2; round 5: 40 -> ~23 VALU instructions per element over the two passes)
+    float xhf[MAXR][8], dyf[MAXR][8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int cl = ch * 8 + e;
@@ -505,10 +515,10 @@ __global__ __launch_bounds__(512, ((PB <= 3 && (TY == 3 || PG_OCC4_ALL)) ? 4 : 2
         const float gg = g1 + (GB ? gv[k].get(e) : 0.f), bb = b1 + (GB ? bv[k].get(e) : 0.f);
         const float xh = (xv[k].get(e) - m) * r;
         const float yv = __builtin_fmaf(xh, gg, bb);            // (norm.hip: mat_value -- the forward's rounding)
-        const bool pos = yv > 0.f;
-        posmask |= pos ? (1ull << (k * 8 + e)) : 0ull;
-        const float dy = dv[k].get(e) * (pos ? 1.f : nneg);
+        const float dvv = dv[k].get(e);
+        const float dy = yv > 0.f ? dvv : dvv * nneg;
         const float dxh = dy * gg;
+        xhf[k][e] = xh; dyf[k][e] = dy;
         q0 += dxh; q1 += dxh * xh; q2 += dy * xh; q3 += dy;
       }
 #pragma unroll
@@ -534,26 +544,29 @@ __global__ __launch_bounds__(512, ((PB <= 3 && (TY == 3 || PG_OCC4_ALL)) ? 4 : 2
     T* dxo = (T*)a.y2 + pix0 * a.y2_pitch + lc;
     T* dgo = a.dgb ? (T*)a.dgb + pix0 * a.dgb_pitch + lc : nullptr;
     const T* rsb = a.res ? (const T*)a.res + pix0 * a.res_pitch + lc : nullptr;
+    float rr2[8], g12[8], s1v[8], s2v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const int cl = ch * 8 + e; rr2[e] = cst[64 + cl]; g12[e] = cst[128 + cl]; s1v[e] = cst[256 + cl]; s2v[e] = cst[320 + cl]; }
 #pragma unroll
     for (int k = 0; k < MAXR; ++k) {
       const int row = r0 + 64 * k;
       if (row >= HW) break;
       Chunk<T> o0, o1, o2;
+      float v0[8], v1[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int cl = ch * 8 + e;
-        const float m = cst[cl], r = cst[64 + cl], gg = cst[128 + cl] + (GB ? gv[k].get(e) : 0.f), s1 = cst[256 + cl], s2 = cst[320 + cl];
-        const float xh = (xv[k].get(e) - m) * r;
-        const float dy = dv[k].get(e) * (((posmask >> (k * 8 + e)) & 1ull) ? 1.f : nneg);
+        const float gg = g12[e] + (GB ? gv[k].get(e) : 0.f);
+        const float xh = xhf[k][e], dy = dyf[k][e];
         const float dxh = dy * gg;
-        o0.set(e, r * (dxh - s1 - xh * s2));
-        o1.set(e, dy * xh);
-        o2.set(e, dy);
+        v0[e] = rr2[e] * (dxh - s1v[e] - xh * s2v[e]);
+        v1[e] = dy * xh;
       }
-      if (rsb) {
+      o0.pack(v0); o1.pack(v1); o2.pack(dyf[k]);
+      if (rsb) {                                                // (added to the ROUNDED dx, as before)
         Chunk<T> rv; rv.raw = *(const u32x4*)(rsb + (size_t)row * a.res_pitch);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o0.set(e, o0.get(e) + rv.get(e));
+        for (int e = 0; e < 8; ++e) v0[e] = o0.get(e) + rv.get(e);
+        o0.pack(v0);
       }
       *(u32x4*)(dxo + (size_t)row * a.y2_pitch) = o0.raw;
       if (dgo) {

@@ -46,9 +46,12 @@ extern "C" int s2p_posenc_fwd(const float* state, int N, int S, int L, float* ou
 template <typename T>
 __global__ void avgpool_fwd_kernel(const T* x, int N, int H, int W, int C, T* y, int Ho, int Wo) {
   long long total = (long long)N * Ho * Wo * C;
+  const bool fast = total < (1ll << 31);
+  const IdxDiv dC(C, fast), dW(Wo, fast), dH(Ho, fast);
   GRID_STRIDE(idx, total) {
-    int c = (int)(idx % C); long long p = idx / C;
-    int ox = (int)(p % Wo); p /= Wo; int oy = (int)(p % Ho); int n = (int)(p / Ho);
+    int c, ox, oy;
+    long long p = dC.split(idx, c);
+    p = dW.split(p, ox); int n = (int)dH.split(p, oy);
     float s = 0.f; int cnt = 0;
     for (int ky = 0; ky < 3; ++ky) {
       int iy = oy * 2 - 1 + ky; if (iy < 0 || iy >= H) continue;
@@ -63,9 +66,12 @@ __global__ void avgpool_fwd_kernel(const T* x, int N, int H, int W, int C, T* y,
 template <typename T>
 __global__ void avgpool_bwd_kernel(const T* dy, int N, int H, int W, int C, T* dx, int Ho, int Wo, int accumulate) {
   long long total = (long long)N * H * W * C;
+  const bool fast = total < (1ll << 31);
+  const IdxDiv dC(C, fast), dW(W, fast), dH(H, fast);
   GRID_STRIDE(idx, total) {
-    int c = (int)(idx % C); long long p = idx / C;
-    int ix = (int)(p % W); p /= W; int iy = (int)(p % H); int n = (int)(p / H);
+    int c, ix, iy;
+    long long p = dC.split(idx, c);
+    p = dW.split(p, ix); int n = (int)dH.split(p, iy);
     float s = 0.f;
     for (int oy = (iy) / 2; oy <= (iy + 1) / 2; ++oy) {     // oy*2-1 <= iy <= oy*2+1
       if (oy < 0 || oy >= Ho) continue;
@@ -105,15 +111,20 @@ __global__ void maxpool_fwd_kernel(const T* x, int N, int H, int W, int C, T* y,
   constexpr int CE = DT<T>::CE;
   int cpr = C / CE;
   long long total = (long long)N * Ho * Wo * cpr;
+  const bool fast = total < (1ll << 31);
+  const IdxDiv dC(cpr, fast), dW(Wo, fast), dH(Ho, fast);
   GRID_STRIDE(idx, total) {
-    int ch = (int)(idx % cpr); long long p = idx / cpr;
-    int ox = (int)(p % Wo); p /= Wo; int oy = (int)(p % Ho); int n = (int)(p / Ho);
+    int ch, ox, oy;
+    long long p = dC.split(idx, ch);
+    p = dW.split(p, ox); int n = (int)dH.split(p, oy);
     const T* b = x + (((size_t)n * H + oy * 2) * W + ox * 2) * C + ch * CE;
     Chunk<T> v00, v01, v10, v11, o;
     v00.raw = *(const u32x4*)b; v01.raw = *(const u32x4*)(b + C);
     v10.raw = *(const u32x4*)(b + (size_t)W * C); v11.raw = *(const u32x4*)(b + (size_t)W * C + C);
+    float ov[CE];
 #pragma unroll
-    for (int e = 0; e < CE; ++e) o.set(e, fmaxf(fmaxf(v00.get(e), v01.get(e)), fmaxf(v10.get(e), v11.get(e))));
+    for (int e = 0; e < CE; ++e) ov[e] = fmaxf(fmaxf(v00.get(e), v01.get(e)), fmaxf(v10.get(e), v11.get(e)));
+    o.pack(ov);
     *(u32x4*)(y + (size_t)idx * CE) = o.raw;
   }
 }
@@ -124,9 +135,12 @@ __global__ void maxpool_bwd_kernel(const T* dy, const T* x, int N, int H, int W,
   constexpr int CE = DT<T>::CE;
   int cpr = C / CE;
   long long total = (long long)N * H * W * cpr;
+  const bool fast = total < (1ll << 31);
+  const IdxDiv dC(cpr, fast), dW(W, fast), dH(H, fast);
   GRID_STRIDE(idx, total) {
-    int ch = (int)(idx % cpr); long long p = idx / cpr;
-    int ix = (int)(p % W); p /= W; int iy = (int)(p % H); int n = (int)(p / H);
+    int ch, ix, iy;
+    long long p = dC.split(idx, ch);
+    p = dW.split(p, ix); int n = (int)dH.split(p, iy);
     int oy = iy >> 1, ox = ix >> 1;
     Chunk<T> o; o.raw = (u32x4){0u, 0u, 0u, 0u};
     if (oy < Ho && ox < Wo) {
@@ -135,14 +149,16 @@ __global__ void maxpool_bwd_kernel(const T* dy, const T* x, int N, int H, int W,
       v[0].raw = *(const u32x4*)b; v[1].raw = *(const u32x4*)(b + C);
       v[2].raw = *(const u32x4*)(b + (size_t)W * C); v[3].raw = *(const u32x4*)(b + (size_t)W * C + C);
       d.raw = *(const u32x4*)(dy + ((((size_t)n * Ho + oy) * Wo + ox) * C + ch * CE));
-      int me = (iy & 1) * 2 + (ix & 1);
+      const int me = (iy & 1) * 2 + (ix & 1);
+      float ov[CE];
 #pragma unroll
       for (int e = 0; e < CE; ++e) {
         float m = v[0].get(e); int am = 0;
 #pragma unroll
         for (int k = 1; k < 4; ++k) { float t = v[k].get(e); if (t > m) { m = t; am = k; } }
-        o.set(e, (am == me && m > 0.f) ? d.get(e) : 0.f);
+        ov[e] = (am == me && m > 0.f) ? d.get(e) : 0.f;
       }
+      o.pack(ov);
     }
     *(u32x4*)(dx + (size_t)idx * CE) = o.raw;
   }
@@ -191,35 +207,51 @@ extern "C" int s2p_resize_nearest(int dtype, const void* x, int N, int H, int W,
 }
 
 // ---- layout ------------------------------------------------------------------------------------------
+// One thread per PIXEL: the C plane reads of consecutive threads are consecutive floats, the pixel's channels leave as whole 16-byte
+// chunks (zero_pad: every chunk of the pitch; otherwise the C channels at c_off, element by element).  Round 1 ran one thread per
+// ELEMENT with two 64-bit divisions each: 9 launches a step, 10 us each, VALU-bound.
 template <typename T>
 __global__ void nchw_to_nhwc_kernel(const float* x, int N, int C, int H, int W, T* y, int pitch, int c_off, int zero_pad) {
-  int span = zero_pad ? pitch : C;        // channels written per pixel (starting at c_off when !zero_pad)
-  long long total = (long long)N * H * W * span;
-  GRID_STRIDE(idx, total) {
-    int j = (int)(idx % span); long long p = idx / span;
-    int hw = (int)(p % ((long long)H * W)); int n = (int)(p / ((long long)H * W));
-    if (zero_pad) {
-      int c = j - c_off;
-      float v = (c >= 0 && c < C) ? x[((size_t)n * C + c) * H * W + hw] : 0.f;
-      y[(size_t)p * pitch + j] = from_f32<T>(v);
+  constexpr int CE = DT<T>::CE;
+  const int HW = H * W;
+  const long long total = (long long)N * HW;
+  const IdxDiv dP(HW, total < (1ll << 31));
+  GRID_STRIDE(p, total) {
+    int hw;
+    const long long n = dP.split(p, hw);
+    const float* xp = x + (size_t)n * C * HW + hw;
+    T* yp = y + (size_t)p * pitch;
+    if (zero_pad && pitch % CE == 0) {
+      for (int cb = 0; cb < pitch; cb += CE) {
+        float v[CE];
+#pragma unroll
+        for (int e = 0; e < CE; ++e) { const int c = cb + e - c_off; v[e] = (c >= 0 && c < C) ? xp[(size_t)c * HW] : 0.f; }
+        Chunk<T> o; o.pack(v);
+        *(u32x4*)(yp + cb) = o.raw;
+      }
+    } else if (zero_pad) {
+      for (int j = 0; j < pitch; ++j) { const int c = j - c_off; yp[j] = from_f32<T>((c >= 0 && c < C) ? xp[(size_t)c * HW] : 0.f); }
     } else {
-      y[(size_t)p * pitch + c_off + j] = from_f32<T>(x[((size_t)n * C + j) * H * W + hw]);
+      for (int j = 0; j < C; ++j) yp[c_off + j] = from_f32<T>(xp[(size_t)j * HW]);
     }
   }
 }
 template <typename T>
 __global__ void nhwc_to_nchw_kernel(const T* x, int pitch, int c_off, int N, int C, int H, int W, float* y, int accumulate) {
   long long total = (long long)N * C * H * W;
+  const bool fast = total < (1ll << 31);
+  const IdxDiv dP(H * W, fast), dC(C, fast);
   GRID_STRIDE(idx, total) {
-    int hw = (int)(idx % ((long long)H * W)); long long q = idx / ((long long)H * W);
-    int c = (int)(q % C); int n = (int)(q / C);
+    int hw, c;
+    long long q = dP.split(idx, hw);
+    int n = (int)dC.split(q, c);
     float v = to_f32(x[((size_t)n * H * W + hw) * pitch + c_off + c]);
     y[idx] = accumulate ? y[idx] + v : v;
   }
 }
 extern "C" int s2p_nchw_to_nhwc(int dtype, const float* x, int N, int C, int H, int W, void* y, int y_pitch, int c_off, int zero_pad, void* stream) {
   if (c_off + C > y_pitch) S2P_FAIL(-1, "s2p_nchw_to_nhwc: channels exceed pitch");
-  long long total = (long long)N * H * W * (zero_pad ? y_pitch : C);
+  long long total = (long long)N * H * W;                                   // one thread per pixel
   if (dtype == S2P_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, N, C, H, W, (float*)y, y_pitch, c_off, zero_pad);
   else if (dtype == S2P_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, N, C, H, W, (__bf16*)y, y_pitch, c_off, zero_pad);
   else S2P_FAIL(-1, "s2p_nchw_to_nhwc: bad dtype");
@@ -259,9 +291,12 @@ __global__ void reflect_fold_kernel(const T* dxp, int N, int H, int W, int C, in
   const int cpr = C / CE;
   const long long total = (long long)N * H * W * cpr;
   const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+  const bool fast = total < (1ll << 31);
+  const IdxDiv dC(cpr, fast), dW(W, fast), dH(H, fast);
   GRID_STRIDE(idx, total) {
-    const int ch = (int)(idx % cpr); long long p = idx / cpr;
-    const int x = (int)(p % W); p /= W; const int y = (int)(p % H); const int n = (int)(p / H);
+    int ch, x, y;
+    long long p = dC.split(idx, ch);
+    p = dW.split(p, x); const int n = (int)dH.split(p, y);
     int ys[3], xs[3], ny = 0, nx = 0;
     ys[ny++] = y + pad; if (y >= 1 && y <= pad) ys[ny++] = pad - y; if (y <= H - 2 && y >= H - 1 - pad) ys[ny++] = 2 * H - 2 - y + pad;
     xs[nx++] = x + pad; if (x >= 1 && x <= pad) xs[nx++] = pad - x; if (x <= W - 2 && x >= W - 1 - pad) xs[nx++] = 2 * W - 2 - x + pad;
@@ -275,8 +310,7 @@ __global__ void reflect_fold_kernel(const T* dxp, int N, int H, int W, int C, in
         for (int e = 0; e < CE; ++e) s[e] += v.get(e);
       }
     Chunk<T> o;
-#pragma unroll
-    for (int e = 0; e < CE; ++e) o.set(e, s[e]);
+    o.pack(s);
     *(u32x4*)(dx + (size_t)idx * CE) = o.raw;
   }
 }
@@ -511,9 +545,27 @@ extern "C" int s2p_adam_step(float* p, const float* g, float* m, float* v, int64
 __global__ void adam_tick_kernel(int* step) { if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1; }
 __global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, long long n4, long long n, float lr,
                                 float beta1, float beta2, float eps, const int* step, float gscale) {
-  const int t = *step;
-  const float bc1 = 1.f - powf(beta1, (float)t), bc2 = 1.f - powf(beta2, (float)t);
-  const float lr_bc1 = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+  // the bias corrections once per workgroup (wave 0, through LDS): two powf calls are ~300 VALU instructions, and with one
+  // 16-byte group per thread every wave of the launch used to run them -- a third of the kernel's instructions (round 5)
+  __shared__ float sc[2];
+  if (threadIdx.x < 64) {
+    const int t = *step;
+    const float bc1 = 1.f - powf(beta1, (float)t), bc2 = 1.f - powf(beta2, (float)t);
+    if (threadIdx.x == 0) { sc[0] = lr / bc1; sc[1] = rsqrtf(bc2); }
+  }
+  __syncthreads();
+  const float lr_bc1 = sc[0], inv_sqrt_bc2 = sc[1];
+  const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+  // p -= lr_bc1 * m / (sqrt(v) * inv_sqrt_bc2 + eps) with the hardware square root and reciprocal (1 ulp each; the update is
+  // ~1e-4 of the parameter, so the parameter moves by < 1e-11 relative against the correctly rounded forms, which cost ~25 VALU
+  // instructions per element more)
+  auto upd = [&](float gg0, float& mm, float& vv, float& pp) {
+    const float gg = gg0 * gscale;
+    mm = __builtin_fmaf(beta1, mm, omb1 * gg);
+    vv = __builtin_fmaf(beta2, vv, omb2 * gg * gg);
+    const float den = __builtin_fmaf(__builtin_amdgcn_sqrtf(vv), inv_sqrt_bc2, eps);
+    pp = __builtin_fmaf(-lr_bc1 * mm, __builtin_amdgcn_rcpf(den), pp);
+  };
   GRID_STRIDE(idx, n4) {
     long long i = idx * 4;
     if (i + 4 <= n) {                       // 16-byte accesses: 28 B / parameter at HBM speed (4-byte accesses ran at 2.6 TB/s)
@@ -521,21 +573,17 @@ __global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, lo
       f32x4 m4 = *(const f32x4*)(m + i), v4 = *(const f32x4*)(v + i), p4 = *(const f32x4*)(p + i);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float gg = g4[e] * gscale;
-        const float mm = beta1 * m4[e] + (1.f - beta1) * gg;
-        const float vv = beta2 * v4[e] + (1.f - beta2) * gg * gg;
-        m4[e] = mm; v4[e] = vv;
-        p4[e] -= lr_bc1 * mm / (sqrtf(vv) * inv_sqrt_bc2 + eps);
+        float mm = m4[e], vv = v4[e], pp = p4[e];
+        upd(g4[e], mm, vv, pp);
+        m4[e] = mm; v4[e] = vv; p4[e] = pp;
       }
       *(f32x4*)(m + i) = m4; *(f32x4*)(v + i) = v4; *(f32x4*)(p + i) = p4;
       continue;
     }
     for (long long k = i; k < n; ++k) {
-      float gg = g[k] * gscale;
-      float mm = beta1 * m[k] + (1.f - beta1) * gg;
-      float vv = beta2 * v[k] + (1.f - beta2) * gg * gg;
-      m[k] = mm; v[k] = vv;
-      p[k] -= lr_bc1 * mm / (sqrtf(vv) * inv_sqrt_bc2 + eps);
+      float mm = m[k], vv = v[k], pp = p[k];
+      upd(g[k], mm, vv, pp);
+      m[k] = mm; v[k] = vv; p[k] = pp;
     }
   }
 }
@@ -544,7 +592,7 @@ extern "C" int s2p_adam_step_dev_part(float* p, const float* g, float* m, float*
   if (n <= 0) return 0;
   long long n4 = (n + 3) / 4;
   if (tick) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_dev);
-  hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for(n4, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, (long long)n,
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for(n4, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, (long long)n,
                      lr, beta1, beta2, eps, (const int*)step_dev, grad_scale);
   S2P_CHECK_LAUNCH("adam_dev_kernel");
   return 0;

@@ -239,6 +239,7 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const NormArgs a) {
     if (gbb) { gv.raw = *(const u32x4*)(gbb + (size_t)p * a.gb_pitch); bv.raw = *(const u32x4*)(gbb + (size_t)p * a.gb_pitch + a.C); }
     if (MODE == 1) dv.raw = *(const u32x4*)(dab + (size_t)p * a.da_pitch);
     Chunk<T> o0, o1, o2;
+    float v0[CE], v1[CE], v2[CE];                     // packed pairwise at the end (Chunk::pack: one conversion per two elements)
 #pragma unroll
     for (int e = 0; e < CE; ++e) {
       float gg = gs[e] + (gbb ? gv.get(e) : 0.f);
@@ -246,15 +247,19 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const NormArgs a) {
       float xh;
       float yv = mat_value(xv.get(e), mean[e], rstd[e], gg, bb, xh);
       if (MODE == 0) {
-        o0.set(e, yv > 0.f ? yv : yv * ns);
+        v0[e] = lrelu_ns(yv, ns);
       } else {
-        float dy = dv.get(e) * (g_tanh ? 1.f - yv * yv : (yv > 0.f ? 1.f : ns));
+        const float dvv = dv.get(e);
+        float dy = yv > 0.f ? dvv : dvv * ns;
+        if (g_tanh) dy = dvv * (1.f - yv * yv);
         float dxh = dy * gg;
-        o0.set(e, rstd[e] * (dxh - s1[e] - xh * s2[e]));
-        o1.set(e, dy * xh);
-        o2.set(e, dy);
+        v0[e] = rstd[e] * (dxh - s1[e] - xh * s2[e]);
+        v1[e] = dy * xh;
+        v2[e] = dy;
       }
     }
+    o0.pack(v0);
+    if (MODE == 1) { o1.pack(v1); o2.pack(v2); }
     if (MODE == 0 && act_generic) {                   // tanh / swish: rare, one uniform branch per chunk
 #pragma unroll
       for (int e = 0; e < CE; ++e) {
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const NormArgs a) {
 // read was an infinity-cache hit), step -0.06 ms.  Half-width slabs at 14 chunks per thread (two workgroups per CU) were measured:
 // 42x42 16.9 vs 21.3 us, 84x84 51 vs 36 us, step +0.06 ms -- not kept.
 template <typename T, int CS, int TH = 1024, bool GB = true, int MP = 0>   // CS = channels per workgroup: 64 (full 128-byte bf16 lines), 32 or 16
-__global__ __launch_bounds__(TH) void in_fused_fwd_kernel(const NormArgs a) {
+__global__ __launch_bounds__(TH, (MP > 14 || TH == 1024) ? 1 : 4) void in_fused_fwd_kernel(const NormArgs a) {     // <= 128 VGPRs but for the 28-chunk form: MP 14 two workgroups per CU, TH 256 four
   constexpr int CE = DT<T>::CE;
   constexpr int NCH = CS / CE, PR = TH / NCH, MAXP = MP ? MP : (TH == 1024 ? (DT<T>::CE == 8 ? 512 : 256) / PR : 8);   // TH 1024: planes of <= 512 (bf16) / 256 (fp32) pixels; TH 512 the same with 8 chunks per thread
   constexpr int RPW = 64 / NCH, NW = TH / 64, MG = GB ? MAXP : 1;
@@ -340,11 +345,19 @@ __global__ __launch_bounds__(TH) void in_fused_fwd_kernel(const NormArgs a) {
   (void)RPW;
   const float inv = 1.f / (float)a.HW;
   float acc[CE], mean[CE], rstd[CE];
+  // KEEP (the plane fits the registers unpacked: every form but the large-plane one): the chunks are unpacked ONCE and the second pass
+  // leaves the centred values for the third; the large-plane form (MP > 0) unpacks in every pass (its payload must stay packed)
+  constexpr bool KEEP = MP == 0;
+  float xf[KEEP ? MAXP : 1][CE];
+  if constexpr (KEEP) {
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) xv[k].unpack(xf[k]);
+  }
 #pragma unroll
   for (int e = 0; e < CE; ++e) {
     acc[e] = 0.f;
 #pragma unroll
-    for (int k = 0; k < MAXP; ++k) acc[e] += xv[k].get(e);            // missing pixels were loaded as zeros
+    for (int k = 0; k < MAXP; ++k) acc[e] += KEEP ? xf[KEEP ? k : 0][e] : xv[k].get(e);      // missing pixels were loaded as zeros
   }
   plane_sum(acc, 0);
   // large-plane form: the payload must stay PACKED between the passes (the compiler would otherwise keep all MAXP * CE unpacked
@@ -360,15 +373,25 @@ __global__ __launch_bounds__(TH) void in_fused_fwd_kernel(const NormArgs a) {
   for (int e = 0; e < CE; ++e) mean[e] = cst[0][cc * CE + e] * inv;
 #pragma unroll
   for (int e = 0; e < CE; ++e) acc[e] = 0.f;
+  // (workgroup-uniform) every thread owns a pixel in each of its first MAXP - 1 slots: only the last slot needs the bounds select
+  const bool full_rows = a.HW >= (MAXP - 1) * PR + PR;
+  auto second_moment = [&](auto fullc) {
+    constexpr bool FULL = decltype(fullc)::value;
 #pragma unroll
-  for (int k = 0; k < MAXP; ++k) {
-    const bool in = pr + k * PR < a.HW;
+    for (int k = 0; k < MAXP; ++k) {
+      const bool in = pr + k * PR < a.HW;
 #pragma unroll
-    for (int e = 0; e < CE; ++e) {
-      const float d = xv[k].get(e) - mean[e];
-      acc[e] += in ? d * d : 0.f;
+      for (int e = 0; e < CE; ++e) {
+        const float d = (KEEP ? xf[KEEP ? k : 0][e] : xv[k].get(e)) - mean[e];
+        if constexpr (KEEP) xf[KEEP ? k : 0][e] = d;
+        if (FULL && k < MAXP - 1) acc[e] = __builtin_fmaf(d, d, acc[e]);
+        else acc[e] += in ? d * d : 0.f;
+      }
     }
-  }
+  };
+  if constexpr (MP > 14) {                                              // (two copies of the pass only where it is 224 elements long)
+    if (full_rows) second_moment(std::integral_constant<bool, true>{}); else second_moment(std::integral_constant<bool, false>{});
+  } else second_moment(std::integral_constant<bool, false>{});
   plane_sum(acc, 1);
   keep_packed();
   if (tid < CS) {
@@ -396,18 +419,21 @@ __global__ __launch_bounds__(TH) void in_fused_fwd_kernel(const NormArgs a) {
     const int p = pr + k * PR;
     if (p >= a.HW) break;
     Chunk<T> o0;
+    float ov[CE];
 #pragma unroll
     for (int e = 0; e < CE; ++e) {
       float gg = gs[e] + ((GB && gbb) ? gv[k % MG].get(e) : 0.f);
       float bb = bs[e] + ((GB && gbb) ? bv[k % MG].get(e) : 0.f);
-      float xh;
-      float yv = mat_value(xv[k].get(e), mean[e], rstd[e], gg, bb, xh);
-      o0.set(e, yv > 0.f ? yv : yv * ns);
+      // mat_value's arithmetic, bit for bit: ((x - mean) * rstd) * gg + bb
+      const float xh = (KEEP ? xf[KEEP ? k : 0][e] : xv[k].get(e) - mean[e]) * rstd[e];
+      ov[e] = lrelu_ns(__builtin_fmaf(xh, gg, bb), ns);
     }
+    o0.pack(ov);
     *(u32x4*)(yb + (size_t)p * a.y_pitch) = o0.raw;
   }
 }
 
+// ------------------------------------------------------------------------------------------------
 // Fused backward for small planes, same geometry as in_fused_fwd_kernel: one workgroup of 1024 threads owns an (image,
 // 64-channel slab) plane, loads x, dL/dy, gamma, beta once (64 VGPRs of 16-byte chunks per thread), forms the four plane
 // sums (wave shuffles + LDS, fixed order) and then writes dx, d(gamma_img | beta_img) and the state-affine gradient from
@@ -504,6 +530,7 @@ __global__ __launch_bounds__(TH) void in_fused_bwd_kernel(const NormArgs a) {
     const int p = pr + k * PR;
     if (p >= a.HW) break;
     Chunk<T> o0, o1, o2;
+    float v0[CE], v1[CE], v2[CE];                        // packed pairwise below (Chunk::pack)
 #pragma unroll
     for (int h4 = 0; h4 < CE / 4; ++h4) {
       const int ch = cc * CE + 4 * h4;
@@ -516,16 +543,18 @@ __global__ __launch_bounds__(TH) void in_fused_bwd_kernel(const NormArgs a) {
         const float xh = (xv[k].get(e) - m4[j]) * r4[j];
         const float dy = dv[k].get(e) * (((posmask >> (k * CE + e)) & (mask_t)1) ? 1.f : gneg);
         const float dxh = dy * gg;
-        o0.set(e, r4[j] * (dxh - s14[j] - xh * s24[j]));
-        o1.set(e, dy * xh);
-        o2.set(e, dy);
+        v0[e] = r4[j] * (dxh - s14[j] - xh * s24[j]);
+        v1[e] = dy * xh;
+        v2[e] = dy;
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (a.res) {                                         // skip-connection gradient folded into the store (fp32 add, one rounding)
+    o0.pack(v0); o1.pack(v1); o2.pack(v2);
+    if (a.res) {                                         // skip-connection gradient folded into the store (added to the ROUNDED dx, as before)
       Chunk<T> rv; rv.raw = *(const u32x4*)((const T*)a.res + img * a.res_pitch + cb0 + (p * a.res_pitch + lc));
 #pragma unroll
-      for (int e = 0; e < CE; ++e) o0.set(e, o0.get(e) + rv.get(e));
+      for (int e = 0; e < CE; ++e) v0[e] = o0.get(e) + rv.get(e);
+      o0.pack(v0);
     }
     *(u32x4*)(yb + (p * a.y_pitch + lc)) = o0.raw;
     if (dgb) {
@@ -651,6 +680,7 @@ extern "C" int s2p_in_apply_fwd(int dtype, const void* x, int N, int HW, int C, 
                                 const void* gb_img, int gb_pitch, const float* gb_st, int gb_st_pitch, int act,
                                 float slope, float eps, void* y, int y_pitch, void* stream) {
   int rc = norm_check("s2p_in_apply_fwd", dtype, C, pitch, gb_pitch, y_pitch); if (rc) return rc;
+  S2P_CHECK_SLOPE("s2p_in_apply_fwd", act, slope);
   NormArgs a{}; a.x = x; a.stats = stats; a.gb = gb_img; a.gbst = gb_st; a.y = y;
   a.N = N; a.HW = HW; a.C = C; a.x_pitch = pitch; a.gb_pitch = gb_pitch; a.gbst_pitch = gb_st_pitch;
   a.y_pitch = y_pitch; a.act = act; a.slope = slope; a.eps = eps;
@@ -672,6 +702,7 @@ extern "C" int s2p_in_norm_fwd(int dtype, const void* x, int N, int HW, int C, i
                                const float* gb_st, int gb_st_pitch, int act, float slope, float eps, void* y, int y_pitch,
                                float* stats, void* stream) {
   int rc = norm_check("s2p_in_norm_fwd", dtype, C, pitch, gb_pitch, y_pitch); if (rc) return rc;
+  S2P_CHECK_SLOPE("s2p_in_norm_fwd", act, slope);
   if (!x || !y || !stats || N <= 0 || HW <= 0) S2P_FAIL(-1, "s2p_in_norm_fwd: null pointer / empty problem");
   const int maxhw = dtype == S2P_F32 ? 256 : 512;
   const bool simple_act = act == S2P_ACT_NONE || act == S2P_ACT_RELU || act == S2P_ACT_LRELU;   // tanh / swish: two-kernel path

@@ -39,6 +39,9 @@ static inline int s2p_env_set(const char*) { return 0; }
 // ---- error plumbing ---------------------------------------------------------
 void s2p_set_error(const char* fmt, ...);
 #define S2P_FAIL(code, ...) do { s2p_set_error(__VA_ARGS__); return (code); } while (0)
+// leaky-relu slopes above 1 are rejected by the forward entry points: the kernels compute  max(v, v * slope)  (lrelu_ns below)
+#define S2P_CHECK_SLOPE(who, act, slope) do { if ((act) == S2P_ACT_LRELU && !((slope) <= 1.f)) \
+    S2P_FAIL(-1, "%s: leaky-relu slope %g > 1 is not supported", who, (double)(slope)); } while (0)
 #define S2P_CHECK_LAUNCH(name) do { hipError_t e_ = hipGetLastError(); \
     if (e_ != hipSuccess) { s2p_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
       return -(int)e_ - 1000; } } while (0)
@@ -62,6 +65,8 @@ template <> struct Chunk<float> {
   // go through a scalar temporary.
   __device__ __forceinline__ float get(int i) const { unsigned u = raw[i]; return __uint_as_float(u); }
   __device__ __forceinline__ void set(int i, float v) { unsigned u = __float_as_uint(v); raw[i] = u; }
+  __device__ __forceinline__ void unpack(float (&v)[4]) const { for (int e = 0; e < 4; ++e) v[e] = get(e); }
+  __device__ __forceinline__ void pack(const float (&v)[4]) { for (int e = 0; e < 4; ++e) set(e, v[e]); }
 };
 template <> struct Chunk<__bf16> {
   u32x4 raw;
@@ -76,7 +81,64 @@ template <> struct Chunk<__bf16> {
     unsigned w = raw[i >> 1];
     raw[i >> 1] = (i & 1) ? ((w & 0x0000ffffu) | ((unsigned)u << 16)) : ((w & 0xffff0000u) | u);
   }
+  // all eight at once.  pack(): one v_cvt_pk_bf16_f32 per PAIR (the same round-to-nearest-even as set(), which costs a conversion and
+  // an insert per element: 1.5 VALU instructions instead of 0.5 -- round 5's instruction-mix counters)
+  __device__ __forceinline__ void unpack(float (&v)[8]) const {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = get(e);
+  }
+  __device__ __forceinline__ void pack(const float (&v)[8]) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bf16x2_t h = {(__bf16)v[2 * e], (__bf16)v[2 * e + 1]};
+      raw[e] = __builtin_bit_cast(unsigned, h);
+    }
+  }
 };
+
+// ---- index arithmetic without integer division ---------------------------------------------------------------------------------
+// m / d and the remainder for 0 <= m < 2^31, d > 0, from a double reciprocal and one correction step each way (the estimate m * (1/d)
+// is within 2^-50 relative of the quotient, so its floor is off by at most one).  An integer division is ~25 (32-bit) to ~100 (64-bit)
+// VALU instructions on gfx950; the pixel -> (image, row, column) splits of the implicit-GEMM prologues and of the element-wise
+// kernels were as much VALU time as everything else those kernels do (round 5: DESIGN.md section 3.12).
+__device__ __forceinline__ double s2p_rcp_f64(int d) {
+  const double x = (double)d;
+  double r = __builtin_amdgcn_rcp(x);                      // v_rcp_f64 is an estimate; two Newton steps reach 2^-52 from 2^-14
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ int divmod_rcp(int m, int d, double rcp, int& rem) {
+  int q = (int)((double)m * rcp);
+  int r = m - q * d;
+  const int lo = r < 0 ? 1 : 0;                            // (selects, not branches)
+  q -= lo; r += lo ? d : 0;
+  const int hi = r >= d ? 1 : 0;
+  q += hi; r -= hi ? d : 0;
+  rem = r;
+  return q;
+}
+// divisor of an element-wise kernel's index split: fast for indices below 2^31 (every launch of the S2P path), plain 64-bit
+// division above.  `fast` is launch-uniform.
+struct IdxDiv {
+  int d; double r; bool fast;
+  __device__ __forceinline__ IdxDiv(int d_, bool fast_) : d(d_), r(fast_ ? s2p_rcp_f64(d_) : 0.0), fast(fast_) {}
+  __device__ __forceinline__ long long split(long long idx, int& rem) const {
+    if (fast) return divmod_rcp((int)idx, d, r, rem);
+    const long long q = idx / d; rem = (int)(idx - q * d); return q;
+  }
+};
+
+// v > 0 ? v : v * ns for ns <= 1 (relu: 0, leaky relu: its slope, none: 1) as one multiply and one maximum instead of multiply,
+// compare and select.  The entry points reject slopes above 1 (s2p_check_slope).
+// (the instruction itself: __builtin_fmaxf puts a canonicalising v_max_f32 x, x in front whenever it cannot prove its operand is one)
+__device__ __forceinline__ float lrelu_ns(float v, float ns) {
+  const float m = v * ns;
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(m));
+  return r;
+}
 
 __device__ __forceinline__ float act_fwd(float v, int act, float slope) {
   switch (act) {

@@ -156,8 +156,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_slab_kernel(const WgSlabArgs a) 
   auto read_frag = [&](const char* ptr) {
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ptr));
     s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ptr + 4 * RS));
-    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, v);
+    // (a concatenation, not eight element inserts: the inserts cost four v_mov_b32 per fragment -- 4.7 VALU instructions per MFMA
+    // in this loop, round 5's instruction-mix counters)
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
   };
   auto main_loop = [&](auto biasc) {
     constexpr bool BIAS = decltype(biasc)::value;

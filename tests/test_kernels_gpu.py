@@ -423,6 +423,29 @@ def test_posenc_losses_adam(hip_device):
         opt.step()
         ops.adam_step(pd, (gr * step).to(dev), m, v, 1e-3, 0.0, 0.9, 1e-8, step)
     assert rel_err(pd.cpu(), pt.detach()) < 1e-5
+    # the graph-capturable form (step counter on the device; hardware sqrt / reciprocal, bias corrections once per workgroup):
+    # same reference, both beta settings of the trainer (TTUR: beta1 = 0), a ragged tail (n % 4 != 0), the two-part call
+    # (tail first with the tick, head second without: Pix2PixTrainer.EARLY_ADAM)
+    for betas in ((0.0, 0.9), (0.5, 0.999)):
+        n = 70003
+        p = torch.randn(n, generator=g); gr = torch.randn(n, generator=g)
+        pt = p.clone().requires_grad_(True)
+        opt = torch.optim.Adam([pt], lr=2e-4, betas=betas, eps=1e-8)
+        pd, m, v = p.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        sd = torch.zeros(1, dtype=torch.int32, device=dev)
+        cut = 40000                       # (a multiple of 4: the head's 16-byte groups stay aligned)
+        for step in range(1, 6):
+            gs = (gr * (1.0 + 0.1 * step)).to(dev)
+            pt.grad = gr.clone() * (1.0 + 0.1 * step)
+            opt.step()
+            if step % 2:
+                ops.adam_step_dev(pd, gs, m, v, 2e-4, betas[0], betas[1], 1e-8, sd)
+            else:
+                ops.adam_step_dev_part(pd[cut:], gs[cut:], m[cut:], v[cut:], 2e-4, betas[0], betas[1], 1e-8, sd, tick=True)
+                ops.adam_step_dev_part(pd[:cut], gs[:cut], m[:cut], v[:cut], 2e-4, betas[0], betas[1], 1e-8, sd, tick=False)
+        assert int(sd.item()) == 5
+        assert rel_err(pd.cpu(), pt.detach()) < 1e-6
+        assert float((pd.cpu() - pt.detach()).abs().max()) < 1e-6          # (a few ulp of parameters of size ~1-4)
 
 
 @pytest.mark.parametrize("case", [
