@@ -43,64 +43,110 @@ extern "C" int s2p_posenc_fwd(const float* state, int N, int S, int L, float* ou
 }
 
 // ---- pooling -----------------------------------------------------------------------------------------
-template <typename T>
+// One thread per (pixel, 16-byte channel chunk) when C is a whole number of chunks (the NHWC pitch of the image tensors: 8), else per
+// element (CH = 1): the window geometry and the index split are shared by the chunk's channels (round 1 ran one thread per element).
+template <typename T, int CH>
 __global__ void avgpool_fwd_kernel(const T* x, int N, int H, int W, int C, T* y, int Ho, int Wo) {
-  long long total = (long long)N * Ho * Wo * C;
+  const int cpr = C / CH;
+  long long total = (long long)N * Ho * Wo * cpr;
   const bool fast = total < (1ll << 31);
-  const IdxDiv dC(C, fast), dW(Wo, fast), dH(Ho, fast);
+  const IdxDiv dC(cpr, fast), dW(Wo, fast), dH(Ho, fast);
   GRID_STRIDE(idx, total) {
     int c, ox, oy;
     long long p = dC.split(idx, c);
     p = dW.split(p, ox); int n = (int)dH.split(p, oy);
-    float s = 0.f; int cnt = 0;
+    float s[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) s[e] = 0.f;
+    int cnt = 0;
     for (int ky = 0; ky < 3; ++ky) {
       int iy = oy * 2 - 1 + ky; if (iy < 0 || iy >= H) continue;
       for (int kx = 0; kx < 3; ++kx) {
         int ix = ox * 2 - 1 + kx; if (ix < 0 || ix >= W) continue;
-        s += to_f32(x[(((size_t)n * H + iy) * W + ix) * C + c]); ++cnt;
+        const T* src = x + (((size_t)n * H + iy) * W + ix) * C + c * CH;
+        if constexpr (CH == 1) s[0] += to_f32(src[0]);
+        else { Chunk<T> v; v.raw = *(const u32x4*)src;
+#pragma unroll
+          for (int e = 0; e < CH; ++e) s[e] += v.get(e); }
+        ++cnt;
       }
     }
-    y[idx] = from_f32<T>(s / (float)cnt);
+    const float fc = (float)cnt;
+    if constexpr (CH == 1) y[idx] = from_f32<T>(s[0] / fc);
+    else { Chunk<T> o;
+#pragma unroll
+      for (int e = 0; e < CH; ++e) s[e] = s[e] / fc;
+      o.pack(s); *(u32x4*)(y + (size_t)idx * CH) = o.raw; }
   }
 }
-template <typename T>
+template <typename T, int CH>
 __global__ void avgpool_bwd_kernel(const T* dy, int N, int H, int W, int C, T* dx, int Ho, int Wo, int accumulate) {
-  long long total = (long long)N * H * W * C;
+  const int cpr = C / CH;
+  long long total = (long long)N * H * W * cpr;
   const bool fast = total < (1ll << 31);
-  const IdxDiv dC(C, fast), dW(W, fast), dH(H, fast);
+  const IdxDiv dC(cpr, fast), dW(W, fast), dH(H, fast);
   GRID_STRIDE(idx, total) {
     int c, ix, iy;
     long long p = dC.split(idx, c);
     p = dW.split(p, ix); int n = (int)dH.split(p, iy);
-    float s = 0.f;
+    float s[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) s[e] = 0.f;
     for (int oy = (iy) / 2; oy <= (iy + 1) / 2; ++oy) {     // oy*2-1 <= iy <= oy*2+1
       if (oy < 0 || oy >= Ho) continue;
       int y0 = oy * 2 - 1, cy = (y0 < 0 ? 2 : 3) - ((y0 + 2 >= H) ? (y0 + 3 - H) : 0);
       for (int ox = (ix) / 2; ox <= (ix + 1) / 2; ++ox) {
         if (ox < 0 || ox >= Wo) continue;
         int x0 = ox * 2 - 1, cx = (x0 < 0 ? 2 : 3) - ((x0 + 2 >= W) ? (x0 + 3 - W) : 0);
-        s += to_f32(dy[(((size_t)n * Ho + oy) * Wo + ox) * C + c]) / (float)(cy * cx);
+        const float fc = (float)(cy * cx);
+        const T* src = dy + (((size_t)n * Ho + oy) * Wo + ox) * C + c * CH;
+        if constexpr (CH == 1) s[0] += to_f32(src[0]) / fc;
+        else { Chunk<T> v; v.raw = *(const u32x4*)src;
+#pragma unroll
+          for (int e = 0; e < CH; ++e) s[e] += v.get(e) / fc; }
       }
     }
-    if (accumulate) s += to_f32(dx[idx]);
-    dx[idx] = from_f32<T>(s);
+    if constexpr (CH == 1) {
+      if (accumulate) s[0] += to_f32(dx[idx]);
+      dx[idx] = from_f32<T>(s[0]);
+    } else {
+      Chunk<T> o;
+      if (accumulate) { o.raw = *(const u32x4*)(dx + (size_t)idx * CH);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) s[e] += o.get(e); }
+      o.pack(s); *(u32x4*)(dx + (size_t)idx * CH) = o.raw;
+    }
   }
 }
 extern "C" int s2p_avgpool3x3s2_fwd(int dtype, const void* x, int N, int H, int W, int C, void* y, void* stream) {
   int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  long long total = (long long)N * Ho * Wo * C;
-  if (dtype == S2P_F32) hipLaunchKernelGGL(avgpool_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x, N, H, W, C, (float*)y, Ho, Wo);
-  else if (dtype == S2P_BF16) hipLaunchKernelGGL(avgpool_fwd_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, N, H, W, C, (__bf16*)y, Ho, Wo);
-  else S2P_FAIL(-1, "s2p_avgpool3x3s2_fwd: bad dtype");
+  const int ce = dtype == S2P_F32 ? 4 : 8;
+  const bool chunks = C % ce == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
+  long long total = (long long)N * Ho * Wo * (chunks ? C / ce : C);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == S2P_F32) {
+    if (chunks) hipLaunchKernelGGL((avgpool_fwd_kernel<float, 4>), dim3(grid_for(total)), dim3(256), 0, st, (const float*)x, N, H, W, C, (float*)y, Ho, Wo);
+    else hipLaunchKernelGGL((avgpool_fwd_kernel<float, 1>), dim3(grid_for(total)), dim3(256), 0, st, (const float*)x, N, H, W, C, (float*)y, Ho, Wo);
+  } else if (dtype == S2P_BF16) {
+    if (chunks) hipLaunchKernelGGL((avgpool_fwd_kernel<__bf16, 8>), dim3(grid_for(total)), dim3(256), 0, st, (const __bf16*)x, N, H, W, C, (__bf16*)y, Ho, Wo);
+    else hipLaunchKernelGGL((avgpool_fwd_kernel<__bf16, 1>), dim3(grid_for(total)), dim3(256), 0, st, (const __bf16*)x, N, H, W, C, (__bf16*)y, Ho, Wo);
+  } else S2P_FAIL(-1, "s2p_avgpool3x3s2_fwd: bad dtype");
   S2P_CHECK_LAUNCH("avgpool_fwd_kernel");
   return 0;
 }
 extern "C" int s2p_avgpool3x3s2_bwd(int dtype, const void* dy, int N, int H, int W, int C, void* dx, int accumulate, void* stream) {
   int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  long long total = (long long)N * H * W * C;
-  if (dtype == S2P_F32) hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, N, H, W, C, (float*)dx, Ho, Wo, accumulate);
-  else if (dtype == S2P_BF16) hipLaunchKernelGGL(avgpool_bwd_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dy, N, H, W, C, (__bf16*)dx, Ho, Wo, accumulate);
-  else S2P_FAIL(-1, "s2p_avgpool3x3s2_bwd: bad dtype");
+  const int ce = dtype == S2P_F32 ? 4 : 8;
+  const bool chunks = C % ce == 0 && (((uintptr_t)dy | (uintptr_t)dx) & 15) == 0;
+  long long total = (long long)N * H * W * (chunks ? C / ce : C);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == S2P_F32) {
+    if (chunks) hipLaunchKernelGGL((avgpool_bwd_kernel<float, 4>), dim3(grid_for(total)), dim3(256), 0, st, (const float*)dy, N, H, W, C, (float*)dx, Ho, Wo, accumulate);
+    else hipLaunchKernelGGL((avgpool_bwd_kernel<float, 1>), dim3(grid_for(total)), dim3(256), 0, st, (const float*)dy, N, H, W, C, (float*)dx, Ho, Wo, accumulate);
+  } else if (dtype == S2P_BF16) {
+    if (chunks) hipLaunchKernelGGL((avgpool_bwd_kernel<__bf16, 8>), dim3(grid_for(total)), dim3(256), 0, st, (const __bf16*)dy, N, H, W, C, (__bf16*)dx, Ho, Wo, accumulate);
+    else hipLaunchKernelGGL((avgpool_bwd_kernel<__bf16, 1>), dim3(grid_for(total)), dim3(256), 0, st, (const __bf16*)dy, N, H, W, C, (__bf16*)dx, Ho, Wo, accumulate);
+  } else S2P_FAIL(-1, "s2p_avgpool3x3s2_bwd: bad dtype");
   S2P_CHECK_LAUNCH("avgpool_bwd_kernel");
   return 0;
 }
@@ -150,15 +196,46 @@ __global__ void maxpool_bwd_kernel(const T* dy, const T* x, int N, int H, int W,
       v[2].raw = *(const u32x4*)(b + (size_t)W * C); v[3].raw = *(const u32x4*)(b + (size_t)W * C + C);
       d.raw = *(const u32x4*)(dy + ((((size_t)n * Ho + oy) * Wo + ox) * C + ch * CE));
       const int me = (iy & 1) * 2 + (ix & 1);
-      float ov[CE];
+      if constexpr (sizeof(T) == 2) {
+        // bf16: two elements per instruction on the raw bit patterns.  Negative inputs are clamped to +0 first (signed 16-bit maximum
+        // with 0) -- a window whose maximum is not positive passes no gradient anyway -- and non-negative bf16 values order like their
+        // bit patterns as unsigned integers.  This position receives the gradient iff it equals the window maximum m, no EARLIER
+        // position does (first arg-max, as the scan  m = v0; if (vk > m) take k  resolves ties), and m > 0.  A 16-bit lane that is
+        // zero becomes the mask 0xffff through  min(z, 1) - 1.  ~14 VALU instructions per element instead of ~26 with the unpack,
+        // compare / select scan and pack (the kernel is VALU-bound: round 5's instruction-mix counters).
+        typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
+        typedef __attribute__((ext_vector_type(2))) short s16x2;
+        const u16x2 one = {1, 1}, zero = {0, 0}, ones = {0xffff, 0xffff};
+        const s16x2 szero = {0, 0};
+        const bool b0 = me > 0, b1 = me > 1, b2 = me > 2;              // position k lies before this one
 #pragma unroll
-      for (int e = 0; e < CE; ++e) {
-        float m = v[0].get(e); int am = 0;
+        for (int j = 0; j < 4; ++j) {
+          u16x2 a[4];
 #pragma unroll
-        for (int k = 1; k < 4; ++k) { float t = v[k].get(e); if (t > m) { m = t; am = k; } }
-        ov[e] = (am == me && m > 0.f) ? d.get(e) : 0.f;
+          for (int k = 0; k < 4; ++k) {
+            const unsigned w = v[k].raw[j];
+            a[k] = __builtin_bit_cast(u16x2, __builtin_elementwise_max(__builtin_bit_cast(s16x2, w), szero));
+          }
+          const u16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(a[0], a[1]), __builtin_elementwise_max(a[2], a[3]));
+          const u16x2 mine = me == 0 ? a[0] : (me == 1 ? a[1] : (me == 2 ? a[2] : a[3]));
+          const u16x2 eq = __builtin_elementwise_min(m - mine, one) - one;                     // 0xffff where mine == m
+          const u16x2 d0 = b0 ? m - a[0] : ones, d1 = b1 ? m - a[1] : ones, d2 = b2 ? m - a[2] : ones;
+          const u16x2 first = zero - __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_min(d0, d1), d2), one);   // 0xffff where every earlier one differs
+          const u16x2 pos = zero - __builtin_elementwise_min(m, one);                         // 0xffff where m > 0
+          const unsigned dw = d.raw[j];
+          o.raw[j] = dw & __builtin_bit_cast(unsigned, eq) & __builtin_bit_cast(unsigned, first) & __builtin_bit_cast(unsigned, pos);
+        }
+      } else {
+        float ov[CE];
+#pragma unroll
+        for (int e = 0; e < CE; ++e) {
+          float m = v[0].get(e); int am = 0;
+#pragma unroll
+          for (int k = 1; k < 4; ++k) { float t = v[k].get(e); if (t > m) { m = t; am = k; } }
+          ov[e] = (am == me && m > 0.f) ? d.get(e) : 0.f;
+        }
+        o.pack(ov);
       }
-      o.pack(ov);
     }
     *(u32x4*)(dx + (size_t)idx * CE) = o.raw;
   }
@@ -592,7 +669,7 @@ extern "C" int s2p_adam_step_dev_part(float* p, const float* g, float* m, float*
   if (n <= 0) return 0;
   long long n4 = (n + 3) / 4;
   if (tick) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_dev);
-  hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for(n4, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, (long long)n,
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for(n4, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, (long long)n,
                      lr, beta1, beta2, eps, (const int*)step_dev, grad_scale);
   S2P_CHECK_LAUNCH("adam_dev_kernel");
   return 0;

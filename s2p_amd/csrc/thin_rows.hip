@@ -273,6 +273,7 @@ __global__ __launch_bounds__(256) void thin_cin_fwd_kernel(const CinArgs a) {
   __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
   const float ns = a.act == S2P_ACT_RELU ? 0.f : (a.act == S2P_ACT_LRELU ? a.slope : 1.f);
   const int HoWo = a.Ho * a.Wo;
+  const double rcpHW = s2p_rcp_f64(HoWo), rcpW = s2p_rcp_f64(a.Wo);
   // bias of this lane's 32 channels, once per workgroup (it was re-loaded for every tile: 32 dependent global loads in each epilogue)
   float bb[2][16];
 #pragma unroll
@@ -290,7 +291,8 @@ __global__ __launch_bounds__(256) void thin_cin_fwd_kernel(const CinArgs a) {
     m = tile * 32 + nl;
     mok = m < a.M;
     const int mm = mok ? m : 0;
-    const int n = mm / HoWo, rr = mm - n * HoWo, oy = rr / a.Wo, ox = rr - oy * a.Wo;
+    int rr, ox;
+    const int n = divmod_rcp(mm, HoWo, rcpHW, rr), oy = divmod_rcp(rr, a.Wo, rcpW, ox);      // (two integer divisions per tile: ~50 of its ~300 VALU instructions)
     unsigned rowoff[KS], coloff[KS];
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
@@ -325,11 +327,11 @@ __global__ __launch_bounds__(256) void thin_cin_fwd_kernel(const CinArgs a) {
     if (more) issue_tile(tile + tstride, nxt, mok_n, m_n);
     const char* wf = smem;
     asm volatile("" : "+v"(wf));                         // opaque per tile: the fragment reads stay in the loop
-    f32x16 acc[2];
+    f32x16 acc[2];                                       // start from the bias: the epilogue's 32 adds are the initialisation
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[ct][e] = 0.f;
+      for (int e = 0; e < 16; ++e) acc[ct][e] = bb[ct][e];
 #pragma unroll
     for (int s = 0; s < NK; ++s) {
       const bf16x8 bf = __builtin_bit_cast(bf16x8, cur[s]);
@@ -348,8 +350,7 @@ __global__ __launch_bounds__(256) void thin_cin_fwd_kernel(const CinArgs a) {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float t = acc[ct][4 * q + e] + bb[ct][4 * q + e];
-          v[e] = t > 0.f ? t : t * ns;
+          v[e] = lrelu_ns(acc[ct][4 * q + e], ns);
         }
         const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
         pk[ct][q] = __builtin_bit_cast(u32x2, o);

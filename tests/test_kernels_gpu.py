@@ -335,6 +335,23 @@ def test_pool_resize_layout(hip_device, dtype):
     assert rel_err(nchw(y, C), yr.detach()) < tol
     dx = ops.avgpool_bwd(nhwc(dy, C, dtype, dev), tuple(xd.shape))
     assert rel_err(nchw(dx, C), xr.grad) < tol
+    if dtype == torch.float32:
+        # a channel count that is not a whole number of 16-byte chunks takes the per-element form of the two kernels (straight
+        # through the C ABI: ops.* always passes a chunk-padded pitch)
+        from s2p_amd._lib import check, dtype_id, lib, ptr, stream
+        x5 = torch.randn(N, 5, H, W, generator=g)
+        x5r = x5.clone().requires_grad_(True)
+        y5r = F.avg_pool2d(x5r, 3, 2, 1, count_include_pad=False)
+        dy5 = torch.randn(y5r.shape, generator=g)
+        y5r.backward(dy5)
+        x5d = x5.permute(0, 2, 3, 1).contiguous().to(dev)
+        y5 = torch.empty(N, y5r.shape[2], y5r.shape[3], 5, device=dev)
+        check(lib().s2p_avgpool3x3s2_fwd(dtype_id(dtype), ptr(x5d), N, H, W, 5, ptr(y5), stream()), "avgpool fwd, C = 5")
+        assert rel_err(y5.permute(0, 3, 1, 2).cpu(), y5r.detach()) < tol
+        dx5 = torch.empty_like(x5d)
+        dy5d = dy5.permute(0, 2, 3, 1).contiguous().to(dev)
+        check(lib().s2p_avgpool3x3s2_bwd(dtype_id(dtype), ptr(dy5d), N, H, W, 5, ptr(dx5), 0, stream()), "avgpool bwd, C = 5")
+        assert rel_err(dx5.permute(0, 3, 1, 2).cpu(), x5r.grad) < tol
     # max pool (+ fused relu mask): x is a relu output
     a = F.relu(x)
     ar = a.clone().requires_grad_(True)
