@@ -41,7 +41,16 @@ struct WgSlabArgs {
   int total_wgs;
 };
 
-template <int WROWS>
+// TBL: the padded raster of one image (Hp * Wp <= WS_TBL_MAX positions) is tabulated in LDS once per workgroup, one table per
+// operand -- position -> byte offset of the pixel inside its image, 0xc0000000 where the position is padding -- and a DMA's source
+// offset is  table[q] + (image offset + chunk offset):  6 VALU instructions per DMA (advance q with one wrap, one add) and one
+// 4-byte LDS read issued a whole block ahead, instead of ~19 for the (n, row, column) state with its bounds tests and two
+// multiplies.  Round 5's instruction-mix counters: the kernel spent 3.7 VALU instructions per MFMA, nearly all of them on these
+// addresses, and 81 % of its time is VALU + MFMA issue.  A padding position adds up to an offset in [2^31 + 2^29, 2^32 - 2^29) and
+// an image index outside [0, N) to one below 0 or beyond the tensor: either way the buffer range check returns zeros (the host
+// keeps the tensors below 2^29 bytes on this path).
+constexpr int WS_TBL_MAX = 768;
+template <int WROWS, bool TBL>
 __global__ __launch_bounds__(256, 2) void wgrad_slab_kernel(const WgSlabArgs a) {
   constexpr int T = 9, RS = 128, NST = 3;
   constexpr int ASTG = 64 * RS;                 // 8 KiB: 64 positions x 64 co
@@ -49,7 +58,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_slab_kernel(const WgSlabArgs a) 
   constexpr int STG = ASTG + XSTG;
   constexpr int NXI = WROWS / 32;               // X DMA instructions per wave per block (8 rows each, 4 waves)
   constexpr int NDMA = 2 + NXI;
-  __shared__ __attribute__((aligned(1024))) char smem[NST * STG];
+  // the tables sit at LDS address 0 (their byte offsets fit a ds_read's immediate: no address arithmetic), the stages behind them
+  constexpr int TOFF = TBL ? 2 * WS_TBL_MAX * 4 : 0;           // [A | B], a multiple of 1 KiB
+  __shared__ __attribute__((aligned(1024))) char lds_all[TOFF + NST * STG];
+  char* const smem = lds_all + TOFF;
+  unsigned* const ptab = (unsigned*)lds_all;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // flattened workgroup id, job-major, spread so that workgroups b, b+8, ... (one XCD) hold consecutive ids: the tiles
@@ -80,25 +93,59 @@ __global__ __launch_bounds__(256, 2) void wgrad_slab_kernel(const WgSlabArgs a) 
   const int a_cbyte = (co_t * 64) * 2, b_cbyte = (ci_s * 64) * 2;
   int pn[NDMA], prr[NDMA], pc[NDMA];
   int cb[NDMA];                                                // chunk byte offset (swizzled) + channel base
+  // TBL: q4 = 4 * (position inside its image's padded raster), noffc = image offset + chunk offset (bytes), tv = the table entry of q
+  unsigned q4[NDMA], noffc[NDMA], tv[NDMA];
+  const int HpWp = a.Hp * a.Wp;
+  if constexpr (TBL) {
+    for (int q = tid; q < HpWp; q += 256) {
+      const int r = q / a.Wp, c = q - r * a.Wp;
+      const bool in = c < a.W && r < a.H;
+      ptab[q] = in ? (unsigned)(r * a.W + c) * (unsigned)(a.a_pitch * 2) : 0xc0000000u;
+      ptab[WS_TBL_MAX + q] = in ? (unsigned)(r * a.W + c) * (unsigned)(a.b_pitch * 2) : 0xc0000000u;
+    }
+    __syncthreads();
+  }
 #pragma unroll
   for (int i = 0; i < NDMA; ++i) {
     const int row = (4 * (i < 2 ? i : i - 2) + wave) * 8 + lrow;
     int pos = b0 * 64 + row - (i < 2 ? 0 : a.halo);
     int nadj = 0;
     if (pos < 0) { pos += a.Hp * a.Wp; nadj = -1; }            // pos >= -halo > -Hp*Wp
-    const int q1 = pos / a.Wp;
-    pc[i] = pos - q1 * a.Wp;
-    const int n = q1 / a.Hp;
-    prr[i] = q1 - n * a.Hp;
-    pn[i] = n + nadj;
     cb[i] = (i < 2 ? a_cbyte : b_cbyte) + ((pch ^ (((row >> 1) & 1) << 2)) * 16);
+    if constexpr (TBL) {
+      const int n = pos / HpWp, q = pos - n * HpWp;
+      q4[i] = (unsigned)q * 4u;
+      noffc[i] = (unsigned)((n + nadj) * (a.H * a.W * (i < 2 ? a.a_pitch : a.b_pitch) * 2) + cb[i]);
+      tv[i] = ptab[(i < 2 ? 0 : WS_TBL_MAX) + q];
+    } else {
+      const int q1 = pos / a.Wp;
+      pc[i] = pos - q1 * a.Wp;
+      const int n = q1 / a.Hp;
+      prr[i] = q1 - n * a.Hp;
+      pn[i] = n + nadj;
+    }
   }
   const int a_pitch2 = a.a_pitch * 2, b_pitch2 = a.b_pitch * 2;
   // 64 positions = adv_n images + adv_r rows + adv_c columns (block-uniform scalars)
   const int adv_q = 64 / a.Wp, adv_c = 64 - adv_q * a.Wp, adv_n = adv_q / a.Hp, adv_r = adv_q - adv_n * a.Hp;
+  // TBL: 64 positions = tadv_n images + tadv_q positions; HpWp4 = 4 Hp Wp
+  const int tadv_n = 64 / HpWp;
+  const unsigned tadv_q4 = (unsigned)(64 - tadv_n * HpWp) * 4u, HpWp4 = (unsigned)HpWp * 4u;
+  const unsigned img_a = (unsigned)(a.H * a.W) * (unsigned)a_pitch2, img_b = (unsigned)(a.H * a.W) * (unsigned)b_pitch2;
   // one DMA (index i of this wave's NDMA per block) of the block the coordinate state points at, then advance that state
   auto issue_one = [&](auto ic, unsigned base) {
     constexpr int i = decltype(ic)::value;
+    if constexpr (TBL) {
+      const unsigned off = tv[i] + noffc[i];
+      if (i < 2) s2p_dma16(ar, base + (4 * i + wave) * 1024, (int)off);
+      else s2p_dma16(br, base + ASTG + (4 * (i - 2) + wave) * 1024, (int)off);
+      const unsigned img = i < 2 ? img_a : img_b;
+      const unsigned qa = q4[i] + tadv_q4;
+      const bool wrap = qa >= HpWp4;
+      q4[i] = wrap ? qa - HpWp4 : qa;
+      noffc[i] += (unsigned)tadv_n * img + (wrap ? img : 0u);
+      tv[i] = *(const unsigned*)((const char*)(ptab + (i < 2 ? 0 : WS_TBL_MAX)) + q4[i]);      // consumed a whole block later
+    } else {
     const bool ok = pc[i] < a.W && prr[i] < a.H && (unsigned)pn[i] < (unsigned)a.N;
     const int pix = __mul24(__mul24(pn[i], a.H) + prr[i], a.W) + pc[i];               // < 2^24 (host-checked)
     int off = __mul24(pix, i < 2 ? a_pitch2 : b_pitch2) + cb[i];
@@ -111,6 +158,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_slab_kernel(const WgSlabArgs a) 
     const bool rw = r >= a.Hp;
     r = rw ? r - a.Hp : r; n += rw ? 1 : 0;
     pc[i] = c; prr[i] = r; pn[i] = n;
+    }
   };
   auto issue = [&](int stage) {
     const unsigned base = lds0 + stage * STG;
@@ -354,9 +402,12 @@ extern "C" int s2p_conv2d_wgrad_batched(const s2p_conv_desc* d, const s2p_wgrad_
   }
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(a.total_wgs);
-  if (a.wrows <= 128) hipLaunchKernelGGL(wgrad_slab_kernel<128>, grid, dim3(256), 0, st, a);
-  else if (a.wrows <= 192) hipLaunchKernelGGL(wgrad_slab_kernel<192>, grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(wgrad_slab_kernel<256>, grid, dim3(256), 0, st, a);
+  // tabulated padded raster (see the kernel): images of <= WS_TBL_MAX padded positions, tensors of <= 2^29 bytes, image offsets that
+  // stay exact in 32 bits; switch 18 of the diagnostics build selects the (n, row, column) state everywhere
+  const bool tbl = a.Hp * a.Wp <= WS_TBL_MAX && a.a_bytes <= (1u << 29) && a.b_bytes <= (1u << 29) && !S2P_DIAG_SWITCH(18);
+  if (a.wrows <= 128) { if (tbl) hipLaunchKernelGGL((wgrad_slab_kernel<128, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((wgrad_slab_kernel<128, false>), grid, dim3(256), 0, st, a); }
+  else if (a.wrows <= 192) { if (tbl) hipLaunchKernelGGL((wgrad_slab_kernel<192, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((wgrad_slab_kernel<192, false>), grid, dim3(256), 0, st, a); }
+  else { if (tbl) hipLaunchKernelGGL((wgrad_slab_kernel<256, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((wgrad_slab_kernel<256, false>), grid, dim3(256), 0, st, a); }
   S2P_CHECK_LAUNCH("wgrad_slab_kernel");
   if (a.S > 1) {
     hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(tiles * 9), dim3(256), 0, st, a);
