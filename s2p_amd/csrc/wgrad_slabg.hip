@@ -47,9 +47,12 @@ struct WgSlabGArgs {
   int wt[SG_MAX_CLS][SG_MAX_T];                  // tap index in dW
   int nblocks, total_wgs;
   unsigned a_bytes, b_bytes;
+  int tbl;                                       // DMA offsets from the tabulated padded raster (sg_body)
 };
 
-template <int T, int NXI>
+// TBL: DMA source offsets from a tabulated padded raster (one table per operand at LDS address 0: wgrad_slab.hip, round 5)
+constexpr int SG_TBL_MAX = 768;
+template <int T, int NXI, bool TBL>
 __device__ __forceinline__ void sg_body(const WgSlabGArgs& a, char* smem, const int cls, const int tile, const int split) {
   constexpr int RS = 128, NST = 3;
   constexpr int ASTG = 64 * RS;                 // 8 KiB: 64 positions x 64 A channels
@@ -76,23 +79,58 @@ __device__ __forceinline__ void sg_body(const WgSlabGArgs& a, char* smem, const 
   const int a_cbyte = (co_t * 64) * 2, b_cbyte = (ci_s * 64) * 2;
   int pn[NDMA], prr[NDMA], pc[NDMA];
   int cb[NDMA];
+  // TBL: q4 = 4 * (position inside its image's padded raster), noffc = image offset + chunk offset (bytes), tv = the table entry of q
+  unsigned q4[NDMA], noffc[NDMA], tv[NDMA];
+  const int HpWp = a.Hp * a.Wp;
+  unsigned* const ptab = (unsigned*)(smem - 2 * SG_TBL_MAX * 4);       // [A | B] in front of the stages (wgrad_slabg_kernel)
+  if constexpr (TBL) {
+    for (int q = tid; q < HpWp; q += 256) {
+      const int r = q / a.Wp, c = q - r * a.Wp;
+      ptab[q] = (c < a.Wa && r < a.Ha) ? (unsigned)(r * a.Wa + c) * (unsigned)(a.a_pitch * 2) : 0xc0000000u;
+      const int sy = r * a.bs + py, sx = c * a.bs + px;          // the parity sub-plane's pixel in the full-resolution tensor
+      ptab[SG_TBL_MAX + q] = (sy < a.Hb && sx < a.Wb) ? (unsigned)(sy * a.Wb + sx) * (unsigned)(a.b_pitch * 2) : 0xc0000000u;
+    }
+    __syncthreads();
+  }
 #pragma unroll
   for (int i = 0; i < NDMA; ++i) {
     const int row = (4 * (i < 2 ? i : i - 2) + wave) * 8 + lrow;
     int pos = b0 * 64 + row - (i < 2 ? 0 : hneg);
     int nadj = 0;
     if (pos < 0) { pos += a.Hp * a.Wp; nadj = -1; }            // pos >= -hneg > -Hp*Wp
-    const int q1 = pos / a.Wp;
-    pc[i] = pos - q1 * a.Wp;
-    const int n = q1 / a.Hp;
-    prr[i] = q1 - n * a.Hp;
-    pn[i] = n + nadj;
     cb[i] = (i < 2 ? a_cbyte : b_cbyte) + ((pch ^ (((row >> 1) & 1) << 2)) * 16);
+    if constexpr (TBL) {
+      const int n = pos / HpWp, q = pos - n * HpWp;
+      q4[i] = (unsigned)q * 4u;
+      noffc[i] = (unsigned)((n + nadj) * (i < 2 ? a.Ha * a.Wa * a.a_pitch * 2 : a.Hb * a.Wb * a.b_pitch * 2) + cb[i]);
+      tv[i] = ptab[(i < 2 ? 0 : SG_TBL_MAX) + q];
+    } else {
+      const int q1 = pos / a.Wp;
+      pc[i] = pos - q1 * a.Wp;
+      const int n = q1 / a.Hp;
+      prr[i] = q1 - n * a.Hp;
+      pn[i] = n + nadj;
+    }
   }
   const int a_pitch2 = a.a_pitch * 2, b_pitch2 = a.b_pitch * 2;
   const int adv_q = 64 / a.Wp, adv_c = 64 - adv_q * a.Wp, adv_n = adv_q / a.Hp, adv_r = adv_q - adv_n * a.Hp;
+  const int tadv_n = 64 / HpWp;
+  const unsigned tadv_q4 = (unsigned)(64 - tadv_n * HpWp) * 4u, HpWp4 = (unsigned)HpWp * 4u;
+  const unsigned img_a = (unsigned)(a.Ha * a.Wa) * (unsigned)a_pitch2, img_b = (unsigned)(a.Hb * a.Wb) * (unsigned)b_pitch2;
   auto issue_one = [&](auto ic, unsigned base) {
     constexpr int i = decltype(ic)::value;
+    if constexpr (TBL) {
+      const unsigned toff = tv[i] + noffc[i];
+      if (i < 2) s2p_dma16(ar, base + (4 * i + wave) * 1024, (int)toff);
+      else s2p_dma16(br, base + ASTG + (4 * (i - 2) + wave) * 1024, (int)toff);
+      const unsigned img = i < 2 ? img_a : img_b;
+      const unsigned qa = q4[i] + tadv_q4;
+      const bool wrap = qa >= HpWp4;
+      q4[i] = wrap ? qa - HpWp4 : qa;
+      noffc[i] += (unsigned)tadv_n * img + (wrap ? img : 0u);
+      tv[i] = *(const unsigned*)((const char*)(ptab + (i < 2 ? 0 : SG_TBL_MAX)) + q4[i]);      // consumed a whole block later
+      return;
+    }
     int off;
     if constexpr (i < 2) {
       const bool ok = pc[i] < a.Wa && prr[i] < a.Ha && (unsigned)pn[i] < (unsigned)a.N;
@@ -216,7 +254,9 @@ __device__ __forceinline__ void sg_body(const WgSlabGArgs& a, char* smem, const 
 template <int NXI>
 __global__ __launch_bounds__(256, 2) void wgrad_slabg_kernel(const WgSlabGArgs a) {
   constexpr int STG = 64 * 128 + NXI * 32 * 128;
-  __shared__ __attribute__((aligned(1024))) char smem[3 * STG];
+  constexpr int TOFF = 2 * SG_TBL_MAX * 4;                    // the two offset tables at LDS address 0 (a multiple of 1 KiB), the stages behind them
+  __shared__ __attribute__((aligned(1024))) char lds_all[TOFF + 3 * STG];
+  char* const smem = lds_all + TOFF;
   // flattened workgroup id, spread so that workgroups b, b+8, ... (one XCD) hold consecutive ids: the tiles of one (class, split)
   // stream the same A / B rows and share that XCD's L2
   int f;
@@ -231,12 +271,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_slabg_kernel(const WgSlabGArgs a
   const int rem = f - a.cls_wg0[cls];
   const int split = rem / a.tiles_per_cls, tile = rem - split * a.tiles_per_cls;
   const int T = a.cls_T[cls];
-  if (T == 8) sg_body<8, NXI>(a, smem, cls, tile, split);
+  if (a.tbl) {
+    if (T == 8) sg_body<8, NXI, true>(a, smem, cls, tile, split);
 #ifdef S2P_DIAG_BUILD
-  else if (T == 2) sg_body<2, NXI>(a, smem, cls, tile, split);
-  else if (T == 1) sg_body<1, NXI>(a, smem, cls, tile, split);
+    else if (T == 2) sg_body<2, NXI, true>(a, smem, cls, tile, split);
+    else if (T == 1) sg_body<1, NXI, true>(a, smem, cls, tile, split);
 #endif
-  else sg_body<4, NXI>(a, smem, cls, tile, split);
+    else sg_body<4, NXI, true>(a, smem, cls, tile, split);
+    return;
+  }
+  if (T == 8) sg_body<8, NXI, false>(a, smem, cls, tile, split);
+#ifdef S2P_DIAG_BUILD
+  else if (T == 2) sg_body<2, NXI, false>(a, smem, cls, tile, split);
+  else if (T == 1) sg_body<1, NXI, false>(a, smem, cls, tile, split);
+#endif
+  else sg_body<4, NXI, false>(a, smem, cls, tile, split);
 }
 
 // dW[tile] += sum over the S partial tiles of the class, in a fixed order (bitwise reproducible).  These layers have few tiles and
@@ -328,6 +377,7 @@ static bool sg_plan(const s2p_conv_desc* d, int cin_real, int cout_real, WgSlabG
   const long long ab = (long long)a.N * a.Ha * a.Wa * a.a_pitch * 2, bb = (long long)a.N * a.Hb * a.Wb * a.b_pitch * 2;
   if (ab >= (1ll << 31) || bb >= (1ll << 31)) return false;
   a.a_bytes = (unsigned)ab; a.b_bytes = (unsigned)bb;
+  a.tbl = (a.Hp * a.Wp <= SG_TBL_MAX && ab <= (1ll << 29) && bb <= (1ll << 29) && !S2P_DIAG_SWITCH(18)) ? 1 : 0;
   a.nblocks = cdiv(npos, 64);
   // classes in order of decreasing tap count (the long workgroups start first)
   const int ncand = s == 2 ? 4 : 2;
