@@ -8,6 +8,7 @@
 //          accumulators in registers; one atomic per accumulator per workgroup at the end.
 // dgrad of these layers has K = taps*8 and a wide N, which the MFMA gather kernel already handles well.
 #include "s2p_common.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 
@@ -503,8 +504,10 @@ __global__ __launch_bounds__(512) void thin_rows7_wgrad_kernel(const Rows7Args a
         if (ok) xv[i] = *(const u32x4*)(a.x + (((size_t)n * a.Hw + iy) * a.Ww + ix) * a.x_pitch + ch * 8);
       }
     }
+    // dY: four threads per pixel (each scatters two of the seven shifted copies below; round 4 gave a pixel's 21 two-byte stores to
+    // ONE thread, i.e. to the first two waves, and the other six waited for them at every row's barrier)
     dv = (u32x4){0u, 0u, 0u, 0u};
-    if (tid < a.W && h < nrows) dv = *(const u32x4*)(a.dy + (((size_t)n * a.H + r0 + h) * a.W + tid) * a.y_pitch);
+    if ((tid >> 2) < a.W && h < nrows) dv = *(const u32x4*)(a.dy + (((size_t)n * a.H + r0 + h) * a.W + (tid >> 2)) * a.y_pitch);
   };
   auto store_row = [&](int h) {
     const int slot = h & 7;
@@ -513,11 +516,15 @@ __global__ __launch_bounds__(512) void thin_rows7_wgrad_kernel(const Rows7Args a
       const int idx = tid + 512 * i, col = idx >> 3, ch = idx & 7;
       if (col < ncols) *(u32x4*)(xring + (slot * R7_XC + col) * R7_XS + ch * 16) = xv[i];
     }
-    if (tid < a.W && h < nrows) {
+    if ((tid >> 2) < a.W && h < nrows) {
+      const int col = tid >> 2, part = tid & 3;
       for (int co = 0; co < a.Cout; ++co) {
         const unsigned short v = (unsigned short)((dv[co >> 1] >> ((co & 1) * 16)) & 0xffff);
 #pragma unroll
-        for (int kx = 0; kx < 7; ++kx) *(unsigned short*)(dyc + ((slot * R7_MR + kx * a.Cout + co) * R7_XC + tid + kx)) = v;
+        for (int u = 0; u < 2; ++u) {
+          const int kx = part + 4 * u;
+          if (kx < 7) *(unsigned short*)(dyc + ((slot * R7_MR + kx * a.Cout + co) * R7_XC + col + kx)) = v;
+        }
       }
     }
   };
@@ -529,6 +536,13 @@ __global__ __launch_bounds__(512) void thin_rows7_wgrad_kernel(const Rows7Args a
   const int m = 16 * mt + l15;
   const bf16x8 zero8 = {};
   typedef __attribute__((ext_vector_type(8))) short s16x8;
+  // A fragments of rows m >= M are zeros.  With M < R7_MR every ring slot has a never-written (zero) row M: such lanes READ that row
+  // instead of selecting zeros behind each of the 21 loads of a row step (4 v_cndmask each: 84 of the step's ~160 VALU instructions;
+  // round 5's instruction-mix counters: 10 VALU instructions per MFMA in this kernel)
+  const bool zrow = M < R7_MR;                           // (launch-uniform)
+  const int mr = (m < M || !zrow) ? m : M;
+  auto row_steps = [&](auto guardc) {
+  constexpr bool GUARD = decltype(guardc)::value;
   for (int h = 0; h < nsteps; ++h) {
     if (h + 1 < nsteps) load_row(h + 1);
     // B fragments of halo row h: [k = 32 c + 8 kg + j][ci = 16 cg + l15]
@@ -546,11 +560,11 @@ __global__ __launch_bounds__(512) void thin_rows7_wgrad_kernel(const Rows7Args a
     for (int ky = 0; ky < 7; ++ky) {
       const int r = h - ky;                              // output row (in the band) that pairs with halo row h under tap row ky
       if (r >= 0 && r < nrows) {                         // workgroup-uniform
-        const __bf16* drow = dyc + ((r & 7) * R7_MR + m) * R7_XC + 8 * kg;
+        const __bf16* drow = dyc + ((r & 7) * R7_MR + mr) * R7_XC + 8 * kg;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          bf16x8 afr = zero8;
-          if (m < M) afr = *(const bf16x8*)(drow + 32 * c);
+          bf16x8 afr = *(const bf16x8*)(drow + 32 * c);
+          if constexpr (GUARD) { if (m >= M) afr = zero8; }
           acc[ky] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[c], acc[ky], 0, 0, 0);
         }
       }
@@ -558,6 +572,8 @@ __global__ __launch_bounds__(512) void thin_rows7_wgrad_kernel(const Rows7Args a
     if (h + 1 < nsteps) store_row(h + 1);                // slot (h + 1) & 7 held row h - 7: nobody reads it any more
     __syncthreads();
   }
+  };
+  if (zrow) row_steps(std::integral_constant<bool, false>{}); else row_steps(std::integral_constant<bool, true>{});
   // D: col = lane & 15 (ci within the group), row = (lane >> 4) * 4 + reg -> m = (kx, co)
   const int ci = cg * 16 + l15;
   if (ci < a.cin_real) {
