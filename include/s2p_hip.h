@@ -29,7 +29,7 @@ extern "C" {
 /* the library is built with -fvisibility=hidden: only the entry points declared here are exported */
 #pragma GCC visibility push(default)
 
-#define S2P_VERSION 122
+#define S2P_VERSION 123
 
 enum { S2P_F32 = 0, S2P_BF16 = 1 };
 enum { S2P_ACT_NONE = 0, S2P_ACT_RELU = 1, S2P_ACT_LRELU = 2, S2P_ACT_TANH = 3, S2P_ACT_SWISH = 4 };
