@@ -126,7 +126,9 @@ def hbm_rows(batch, size, version):
     q = size // 2
     known = [("conv_planeg_kernel<3, 3, 3, 384, 6, 0, false, false>", str(batch * (size // 2) * 512) + "x1x1", batch * size * size * 64 * 2 / 1e6,
               "VGG conv1_2 64->64 at %dx%d as 2-row bands (input %dx%dx64)" % (size, size, size, size)),
-             ("conv_dma_kernel<64, 128, 2, 2>", None, batch * q * q * 128 * 2 / 1e6,
+             # (its grid: four phases x the pixel tiles of a phase rounded up to a multiple of 8, 256 threads each -- the 64-row weight
+             # tile also serves the PatchGAN stride-2 dgrads, which must not be mistaken for it)
+             ("conv_dma_kernel<64, 128, 2, 2>", "%dx1x1" % (4 * 8 * (((batch * q * q + 127) // 128 + 7) // 8) * 256), batch * q * q * 128 * 2 / 1e6,
               "decoder transposed conv 128->64 %d->%d (input %dx%dx128), four sub-pixel phases" % (q, size, q, q))]
     amp = []
     for name, grid, in_mb, what in known:
