@@ -68,6 +68,9 @@ const char* s2p_last_error(void);
 /* ---- conv family (replaces torch.nn.functional.conv2d / conv_transpose2d and their
  *      autograd backward: cudnn_convolution_backward_input / _weight) ---------------- */
 /* w_fwd : packed [groups][Cout][KH*KW][Cin]      (for transposed==1 too)               */
+/* act == S2P_ACT_LRELU: slope must be <= 1 in every FORWARD entry point of this header (conv, fused conv + norm,
+ * InstanceNorm forward / apply): the kernels evaluate  max(v, v * slope)  -- one multiply and one maximum; a larger slope is
+ * rejected with an error (s2p_last_error).  The reference uses 0.2 everywhere (LeakyReLU(0.2): SPEC.md).                    */
 int s2p_conv2d_fwd(const s2p_conv_desc* d, const void* x, const void* w_fwd, const float* bias,
                    const void* aux, void* y, int act, float slope, int epi, void* stream);
 /* dx = d(loss)/dx.  w_bwd : packed [groups][Cin][KH*KW][Cout_pad] (the transpose of w_fwd).

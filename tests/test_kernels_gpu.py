@@ -465,6 +465,23 @@ def test_posenc_losses_adam(hip_device):
         assert float((pd.cpu() - pt.detach()).abs().max()) < 1e-6          # (a few ulp of parameters of size ~1-4)
 
 
+@pytest.mark.gpu
+def test_leaky_relu_slope_above_one_is_rejected(hip_device):
+    """The forward kernels evaluate LeakyReLU as max(v, v * slope) (one multiply, one maximum): exact for slopes <= 1, so the entry
+    points refuse a larger one instead of computing something else (include/s2p_hip.h)."""
+    dev = hip_device
+    x = torch.randn(2, 9, 9, 64, device=dev).bfloat16()
+    with pytest.raises(RuntimeError, match="slope"):
+        ops.in_norm_fwd(x, 64, act=ops.ACT_LRELU, slope=1.5)
+    y, _ = ops.in_norm_fwd(x, 64, act=ops.ACT_LRELU, slope=1.0)        # the boundary is allowed (and is the identity)
+    y0, _ = ops.in_norm_fwd(x, 64, act=ops.ACT_NONE)
+    assert torch.equal(y, y0)
+    geom = ops.ConvGeom(64, 64, 3, 1, 1)
+    w = torch.randn(64, 9, 64, device=dev).bfloat16()
+    with pytest.raises(RuntimeError, match="slope"):
+        ops.conv_fwd(geom, x, w, None, 64, act=ops.ACT_LRELU, slope=2.0)
+
+
 @pytest.mark.parametrize("case", [
     # n_jobs, cin, cout, H, W, N, grouped
     (3, 64, 128, 9, 7, 3, False),       # ragged grid, several K blocks, pad rows / columns crossing block boundaries
