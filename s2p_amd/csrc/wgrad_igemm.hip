@@ -28,7 +28,6 @@ struct WgradArgs {
   // [unit][part_rows][part_cols] (and bias partials to part_b [unit][part_rows]); wgrad_part_reduce_kernel adds them to
   // dW / db in unit order.  part == nullptr: fp32 atomics straight into dW / db.
   float* part; float* part_b; int part_rows, part_cols;
-  int tbl_off, tbl_q, tbl_slots;   // wgrad_dma_kernel<.., TBL>: bytes of LDS in front of the stages, entries per tap table, tables (1 or 2)
   int tap[64];
 };
 
@@ -205,13 +204,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 // ds_read_b64_tr_b16 conflict-free (one image serves the 32x32x16 A and B fragments).
 // Workgroups of B-tile 0 also accumulate the bias gradient  db[a] += sum_m A[m][a]  with one extra MFMA against a
 // ones fragment per A fragment, so dY is not read a second time by a separate reduction kernel.
-// TBL (round 5): the gathered operand's source offsets come from a table in LDS -- position of the output grid -> byte offset of the
-// tap's input pixel inside its image, 0xc0000000 where the tap falls outside -- one table per tap the workgroup's 128 B columns
-// touch (two at most: Cb % 64 == 0).  8 VALU instructions per gathered row and step, 1 per A row, instead of ~45 with the
-// (n, row, column) state, its bounds / reflection tests, three multiplies and a `while` loop per row: the kernel spent 12 VALU
-// instructions per MFMA (wgrad_slab.hip has the scheme and the offset arithmetic that makes invalid entries and images outside
-// [0, N) land beyond the buffer).
-constexpr int WD_TBL_Q = 1792;                         // positions per image the tables hold (42 x 42 = 1764)
+// TBL (round 5): the gathered operand's source offsets come from two small tables in LDS per tap -- output row -> byte offset of the
+// tap's input row inside its image, output column -> byte offset of the tap's input pixel inside its row, 0xc0000000 where the tap
+// falls outside (reflection folded in) -- for the (at most two: Cb % 64 == 0) taps the workgroup's 128 B columns touch.  A gathered
+// row costs 11 VALU instructions and two 4-byte LDS reads per step (advance the (row, column) state with one wrap each, add the two
+// entries and the image offset), an A row one add, instead of ~45 with the bounds / reflection tests, three multiplies and a `while`
+// loop per row: the kernel spent 12 VALU instructions per MFMA.  An entry of 0xc0000000 (or two: the sum wraps to 0x80000000) and an
+// image index outside [0, N) put the offset beyond the buffer: the LDS-DMA's range check supplies the zeros (tensors <= 2^29 bytes on
+// this path).  A full position table (wgrad_slab.hip's scheme) was tried first: 3 528 entries built by every workgroup for the 23 K
+// steps it runs cost more than they saved, and their 14 KB took the third workgroup off a CU.
+constexpr int WD_TBL_DIM = 128;                        // output rows / columns the tables hold
 template <int BKP, int NST = 3, bool FUSE_DB = true, bool TBL = false>
 __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
   typedef __bf16 T;
@@ -219,17 +221,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
   constexpr int NP = BKP / 16;                        // DMA pieces (4 rows) per wave per operand per step
   constexpr int TILE = BKP * RS;                      // 8 KiB per operand
   // NST pipeline stages: 3 = two K steps of LDS-DMA in flight behind the MFMAs; 2 = one (32 KiB LDS: 4 workgroups per CU)
-  // TBL: the tables at LDS address 0 (a.tbl_off bytes, a multiple of 1 KiB, sized by the host for this layer's grid and tap count: a
-  // fixed 14 KB cost the 21 x 21 layers their third workgroup per CU), the stages behind them; dynamic LDS
-  char* smem; unsigned* ptab;
-  if constexpr (TBL) {
-    extern __shared__ __attribute__((aligned(1024))) char wd_dyn[];
-    smem = wd_dyn + a.tbl_off; ptab = (unsigned*)wd_dyn;
-  } else {
-    __shared__ __attribute__((aligned(1024))) char wd_static[NST * 2 * TILE];
-    smem = wd_static; ptab = nullptr;
-  }
-  const int tbl_q = a.tbl_q;                          // entries between the two taps' tables
+  __shared__ __attribute__((aligned(1024))) char smem[NST * 2 * TILE];
+  __shared__ unsigned ptab[TBL ? 2 * 2 * WD_TBL_DIM : 1];       // [tap slot][rows | columns]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // XCD-aware mapping: workgroups b, b+8, ... share an XCD (and its 4 MiB L2).  All tiles of one (group, split)
@@ -278,59 +271,63 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
   if (nsteps <= 0) return;
 
   int pm[NP], pn[NP], py[NP], px[NP];
-  unsigned q4[NP], noffc[NP], tv[NP], ao[NP];              // TBL state (see the kernel's header)
+  unsigned noffc[NP], ao[NP];                               // TBL state (see the kernel's header)
+  int oyv[NP], oxv[NP];
+  unsigned tvy[NP], tvx[NP];
   const int bt0 = (b_tile * BT) / a.Cb;                     // first tap of this workgroup's B columns
   if constexpr (TBL) {
-    for (int e = tid; e < 2 * QQ; e += 256) {
-      const int sl = e >= QQ ? 1 : 0, qq = e - sl * QQ;
+    for (int e = tid; e < 2 * 2 * WD_TBL_DIM; e += 256) {
+      const int sl = e / (2 * WD_TBL_DIM), r2 = e - sl * (2 * WD_TBL_DIM), isx = r2 / WD_TBL_DIM, o = r2 - isx * WD_TBL_DIM;
       unsigned v = 0xc0000000u;
-      if (bt0 + sl < a.T) {
+      if (bt0 + sl < a.T && o < (isx ? a.Qw : a.Qh)) {
         const int tw = a.tap[bt0 + sl];
-        const int oy = qq / a.Qw, ox = qq - oy * a.Qw;
-        int iy = oy * a.istride + (int)(signed char)(tw & 0xff), ix = ox * a.istride + (int)(signed char)((tw >> 8) & 0xff);
-        if (a.reflect) {
-          iy = iy < 0 ? -iy : (iy >= a.Hi ? 2 * a.Hi - 2 - iy : iy);
-          ix = ix < 0 ? -ix : (ix >= a.Wi ? 2 * a.Wi - 2 - ix : ix);
-        }
-        if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) v = (unsigned)(iy * a.Wi + ix) * (unsigned)(a.b_pitch * 2);
+        const int lim = isx ? a.Wi : a.Hi;
+        int iv = o * a.istride + (int)(signed char)(isx ? ((tw >> 8) & 0xff) : (tw & 0xff));
+        if (a.reflect) iv = iv < 0 ? -iv : (iv >= lim ? 2 * lim - 2 - iv : iv);
+        if (iv >= 0 && iv < lim) v = (unsigned)iv * (unsigned)((isx ? 1 : a.Wi) * a.b_pitch * 2);
       }
-      if (sl < a.tbl_slots) ptab[sl * tbl_q + qq] = v;
+      ptab[e] = v;
     }
     __syncthreads();
   }
-  const unsigned* const mytab = ptab + (b_ok && bt > bt0 ? tbl_q : 0);      // (bt - bt0 is 0 or 1: Cb % 64 == 0)
+  const unsigned* const ytab = ptab + (b_ok && bt > bt0 ? 2 * WD_TBL_DIM : 0);      // (bt - bt0 is 0 or 1: Cb % 64 == 0)
+  const unsigned* const xtab = ytab + WD_TBL_DIM;
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     int m = step0 * BKP + (4 * i + wave) * 4 + lrow;
     pm[i] = m;
     if constexpr (TBL) {
-      const int n = m / QQ, qq = m - n * QQ;
-      q4[i] = (unsigned)qq * 4u;
+      const int n = m / QQ, rr = m - n * QQ, qy = rr / a.Qw, qx = rr - qy * a.Qw;
+      oyv[i] = qy; oxv[i] = qx;
       noffc[i] = (unsigned)n * (unsigned)(a.Hi * a.Wi * a.b_pitch * 2) + (unsigned)(bc * 2);
       ao[i] = a_ok ? (unsigned)((m * a.a_pitch + a_ch) * 2) : OOB;      // rows beyond M lie beyond the buffer (a_bytes = M * pitch)
-      tv[i] = b_ok ? mytab[qq] : 0u;
+      tvy[i] = ytab[qy]; tvx[i] = xtab[qx];
     } else {
       int n = m / QQ, rr = m - n * QQ, qy = rr / a.Qw, qx = rr - qy * a.Qw;
       pn[i] = n; py[i] = qy; px[i] = qx;
     }
   }
-  const int tadv_n = BKP / QQ;
-  const unsigned tadv_q4 = (unsigned)(BKP - tadv_n * QQ) * 4u, QQ4 = (unsigned)QQ * 4u;
+  // BKP positions = tadv_n images + tadv_y rows + tadv_x columns (launch-uniform)
+  const int tadv_q = BKP / a.Qw, tadv_x = BKP - tadv_q * a.Qw, tadv_n = tadv_q / a.Qh, tadv_y = tadv_q - tadv_n * a.Qh;
   const unsigned img_b = (unsigned)(a.Hi * a.Wi) * (unsigned)(a.b_pitch * 2), a_step = (unsigned)(BKP * a.a_pitch * 2);
   auto issue = [&](int buf) {
     const unsigned base = s2p_lds_addr(smem) + buf * 2 * TILE + wave * (4 * RS);
     if constexpr (TBL) {
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
-        const unsigned bo = b_ok ? tv[i] + noffc[i] : OOB;
+        const unsigned bo = b_ok ? tvy[i] + tvx[i] + noffc[i] : OOB;
         s2p_dma16(ar, base + i * (16 * RS), (int)ao[i]);
         s2p_dma16(br, base + TILE + i * (16 * RS), (int)bo);
         ao[i] += a_step;
-        const unsigned qa = q4[i] + tadv_q4;
-        const bool wrap = qa >= QQ4;
-        q4[i] = wrap ? qa - QQ4 : qa;
-        noffc[i] += (unsigned)tadv_n * img_b + (wrap ? img_b : 0u);
-        tv[i] = *(const unsigned*)((const char*)mytab + q4[i]);      // consumed a whole step later
+        int x = oxv[i] + tadv_x;
+        const bool cw = x >= a.Qw;
+        x = cw ? x - a.Qw : x;
+        int y = oyv[i] + tadv_y + (cw ? 1 : 0);
+        const bool rw = y >= a.Qh;
+        y = rw ? y - a.Qh : y;
+        noffc[i] += (unsigned)tadv_n * img_b + (rw ? img_b : 0u);
+        oxv[i] = x; oyv[i] = y;
+        tvy[i] = ytab[y]; tvx[i] = xtab[x];                        // consumed a whole step later
       }
       return;
     }
@@ -699,14 +696,9 @@ extern "C" int s2p_conv2d_wgrad_ws(const s2p_conv_desc* d, const void* x, const 
       dim3 grid1(8 * cdiv((long long)tiles * units, 8));
       // gathered-operand offsets from LDS tables (see the kernel): two taps per B tile at most, an output grid the tables hold,
       // tensors below 2^29 bytes; switch 19 of the diagnostics build keeps the (n, row, column) state
-      const bool tbl = dense && a.Cb % 64 == 0 && a.Qh * a.Qw <= WD_TBL_Q && a.a_bytes <= (1u << 29) && a.b_bytes <= (1u << 29) &&
+      const bool tbl = dense && a.Cb % 64 == 0 && a.Qh <= WD_TBL_DIM && a.Qw <= WD_TBL_DIM && a.a_bytes <= (1u << 29) && a.b_bytes <= (1u << 29) &&
                        !S2P_DIAG_SWITCH(19);
-      if (tbl) {
-        a.tbl_slots = a.Cb % 128 == 0 ? 1 : 2;           // taps a workgroup's 128 B columns touch
-        a.tbl_q = a.Qh * a.Qw;
-        a.tbl_off = (a.tbl_slots * a.tbl_q * 4 + 1023) / 1024 * 1024;
-        hipLaunchKernelGGL((wgrad_dma_kernel<32, 3, true, true>), grid1, dim3(256), (size_t)a.tbl_off + 3 * 2 * 32 * 256, st, a);
-      }
+      if (tbl) hipLaunchKernelGGL((wgrad_dma_kernel<32, 3, true, true>), grid1, dim3(256), 0, st, a);
       else if (dense) hipLaunchKernelGGL(wgrad_dma_kernel<32>, grid1, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((wgrad_dma_kernel<32, 2, false>), grid1, dim3(256), 0, st, a);
       S2P_CHECK_LAUNCH("wgrad_dma_kernel");
