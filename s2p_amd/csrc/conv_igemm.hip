@@ -1322,10 +1322,10 @@ static int launch_fast(GatherArgs& a, int groups, hipStream_t st) {
   // (backward) the conv in the epilogue), VGG conv4_x on 10x10 maps: the generalised plane-resident kernel (conv_planeg.hip)
   if (!no_plane && !S2P_DIAG_SWITCH(0) && !(a.T == 9 && S2P_DIAG_SWITCH(2)) && !no_dma && groups == 1 && a.nphase == 0 && a.ostride == 1 && a.oy0 == 0 && a.ox0 == 0 && a.Qh == a.Ho &&
       a.Qw == a.Wo && a.M % (a.Qh * a.Qw) == 0 && !a.reflect) {
-    PlaneGProblem pr{a.M / (a.Qh * a.Qw), a.Hi, a.Wi, a.Ho, a.Wo, a.Cin, a.Cout, a.Cst, a.x_pitch, a.y_pitch, a.istride, a.T, a.tap};
+    PlaneGProblem pr{a.M / (a.Qh * a.Qw), a.Hi, a.Wi, a.Ho, a.Wo, a.Cin, a.Cout, a.Cst, a.x_pitch, a.y_pitch, a.istride, a.T, a.tap, a.mat != nullptr};
     PlaneGArgs p{};
     if (s2p_conv_planeg_setup(pr, p)) {
-      const bool fuse = a.mat && p.nbands == 1 && !a.mat->gb && a.act == S2P_ACT_NONE && a.epi != S2P_EPI_MUL_ACTGRAD;
+      const bool fuse = a.mat && p.nbands == 1 && p.gimg == 1 && !a.mat->gb && a.act == S2P_ACT_NONE && a.epi != S2P_EPI_MUL_ACTGRAD;
       if (fuse) *a.mat_done = 1;
       if (a.plan) return 0;                                // no scratch
       p.x = a.x; p.w = a.w; p.bias = a.bias; p.aux = a.aux; p.aux2 = a.aux2; p.y = a.y;

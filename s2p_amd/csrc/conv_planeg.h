@@ -33,12 +33,14 @@ struct PlaneGArgs {
   int nco, img_xcd;               // set by the launcher: Cout / 64; all row bands of an image on one XCD
   int R, nbands;                     // produced rows per workgroup and bands per image (R = Ho, 1: the whole plane)
   int shape;                         // index of the instantiated tile shape (set by s2p_conv_planeg_setup)
+  int gimg, Hst;                     // images stacked in one plane (1: Hst = 2^20) and raster rows from one image to the next
 };
 
 // which == 0: would the kernel take this problem?  (no launch)
 struct PlaneGProblem {
   int N, Hi, Wi, Ho, Wo, Cin, Cout, Cst, x_pitch, y_pitch, istride, T;
   const int* tap;                    // GatherArgs::tap entries: (widx << 16) | ((dx & 0xff) << 8) | (dy & 0xff)
+  bool want_mat;                     // the caller will ask for a fused norm: one image per plane
 };
 bool s2p_conv_planeg_setup(const PlaneGProblem& p, PlaneGArgs& a);      // fills the geometry fields of `a`; false: not applicable
 int s2p_conv_planeg_launch(PlaneGArgs& a, int groups, hipStream_t st);

@@ -102,15 +102,19 @@ __global__ __launch_bounds__(512, ((PB <= 3 && (TY == 3 || PG_OCC4_ALL)) ? 4 : 2
     if (a.img_xcd) {
       const int xcd = bid & 7, k = bid >> 3;
       cs = k % nco; band = (k / nco) % a.nbands; img = (k / (nco * a.nbands)) * 8 + xcd;
-    } else if (((a.N * a.nbands) & 7) == 0) {
+    } else if ((((a.N / a.gimg) * a.nbands) & 7) == 0) {          // (planes: N / gimg images-per-plane groups x bands)
       const int xcd = bid & 7, k = bid >> 3; cs = k % nco; const int pl = (k / nco) * 8 + xcd; img = pl / a.nbands; band = pl - img * a.nbands;
     } else { cs = bid % nco; const int pl = bid / nco; img = pl / a.nbands; band = pl - img * a.nbands; }
   }
   const int r0 = band * a.R;                                   // first produced row of this band (0 when the plane is the whole image)
   const int co_base = cs * 64;
   const int rows_here = a.Ho - r0 < a.R ? a.Ho - r0 : a.R;
-  const int HW = rows_here * a.Wo;                             // pixels this workgroup produces
-  const size_t pix0 = (size_t)img * a.Ho * a.Wo + (size_t)r0 * a.Wo;      // index of its first pixel in the produced tensor
+  // gimg > 1 (round 5, planes of a few dozen pixels without a fused norm: VGG conv5_1 on 5 x 5 maps): `img` counts PLANES of gimg
+  // consecutive images stacked in one padded raster, Hst raster rows apart (an image's rows + the zero row it shares with the next);
+  // their produced pixels are consecutive in the NHWC tensor, so everything behind the K loop sees one plane of gimg * Ho * Wo pixels
+  const int G = a.gimg;
+  const int HW = G > 1 ? G * a.Ho * a.Wo : rows_here * a.Wo;  // pixels this workgroup produces
+  const size_t pix0 = (size_t)img * G * a.Ho * a.Wo + (size_t)r0 * a.Wo;      // index of its first pixel in the produced tensor
 
   const T* xg = (const T*)a.x + (size_t)g * a.x_gstride;
   const T* wg = (const T*)a.w + (size_t)g * a.w_gstride;
@@ -126,22 +130,24 @@ __global__ __launch_bounds__(512, ((PB <= 3 && (TY == 3 || PG_OCC4_ALL)) ? 4 : 2
   //      hv: source offset of this lane's 16 bytes (parity 0 in the parity form), hm: bit pp set where parity pp's pixel exists.
   int hv[PPW]; unsigned hdst[PPW]; int hm[PPW];
   {
-    const float rwp = 1.0f / (float)a.WP;
+    const float rwp = 1.0f / (float)a.WP, rhst = 1.0f / (float)a.Hst;
 #pragma unroll
     for (int k = 0; k < PPW; ++k) {
       const int ii = wave + 8 * k;
       const int cp = ii & 1, pg = ii >> 1;
       const int pos = 32 * pg + (lane >> 1);
       const int row = (int)(((float)pos + 0.5f) * rwp), col = pos - row * a.WP;      // exact for pos < 2^20
-      const int yi = row - a.PT + r0, xi = col - a.PL;      // (bands: stride-1 form only -- produced row r reads gathered rows r - PT ..)
-      const bool in = yi >= 0 && yi < a.Hs && xi >= 0 && xi < a.Ws;
+      const int gi = (int)(((float)row + 0.5f) * rhst);       // image of the stacked raster (0 when gimg == 1: Hst is huge then)
+      const int yi = row - gi * a.Hst - a.PT + r0, xi = col - a.PL;      // (bands: stride-1 form only -- produced row r reads gathered rows r - PT ..)
+      const bool in = yi >= 0 && yi < a.Hs && xi >= 0 && xi < a.Ws && gi < G;
+      const int simg = img * G + gi;
       int m = 0;
       if constexpr (S2D) {
         if (in) m = 1 | (2 * xi + 1 < a.W ? 2 : 0) | (2 * yi + 1 < a.H ? 4 : 0) | ((2 * xi + 1 < a.W && 2 * yi + 1 < a.H) ? 8 : 0);
-        hv[k] = (int)((((unsigned)(img * a.H + 2 * yi) * a.W + 2 * xi) * a.x_pitch) * 2u + (2 * cp + (lane & 1)) * 16);
+        hv[k] = (int)((((unsigned)(simg * a.H + 2 * yi) * a.W + 2 * xi) * a.x_pitch) * 2u + (2 * cp + (lane & 1)) * 16);
       } else {
         m = in ? 1 : 0;
-        hv[k] = (int)((((unsigned)(img * a.H + yi) * a.W + xi) * a.x_pitch) * 2u + (2 * cp + (lane & 1)) * 16);
+        hv[k] = (int)((((unsigned)(simg * a.H + yi) * a.W + xi) * a.x_pitch) * 2u + (2 * cp + (lane & 1)) * 16);
       }
       hm[k] = m;
       hdst[k] = (unsigned)(cp * CPS + pg * 1024);
@@ -192,12 +198,13 @@ __global__ __launch_bounds__(512, ((PB <= 3 && (TY == 3 || PG_OCC4_ALL)) ? 4 : 2
   // ---- fragment read bases ---------------------------------------------------------------------------------------------
   int bB[PB][TY];
   {
-    const float rw = 1.0f / (float)a.Wo;
+    const float rw = 1.0f / (float)a.Wo, rho = G > 1 ? 1.0f / (float)a.Ho : 0.f;     // (one image: yt < Ho or a band's row -> gi = 0)
 #pragma unroll
     for (int j = 0; j < PB; ++j) {
       int m = (wq * PB + j) * 16 + l15;
       if (m >= HW) m = HW - 1;                                 // padding columns of the last block: computed, never stored
-      const int y = (int)(((float)m + 0.5f) * rw), x = m - y * a.Wo;
+      const int yt = (int)(((float)m + 0.5f) * rw), x = m - yt * a.Wo;             // row over all images of the plane
+      const int gi = (int)(((float)yt + 0.5f) * rho), y = yt - gi * a.Ho + gi * a.Hst;   // -> raster row of the stacked planes
 #pragma unroll
       for (int ty = 0; ty < TY; ++ty) bB[j][ty] = (q >> 1) * CPS + (q & 1) * 16 + ((y + ty) * a.WP + x) * 32;
     }
@@ -594,10 +601,27 @@ constexpr int PG_BAND_SHAPE = 5;             // the shape that takes ROW BANDS o
 constexpr int PG_BAND_SHAPE_SHORTK = 6;      // ... when the K loop is short (Cin = 64; measured: 128 -> 128 at 42x42 is 2 % faster on the large bands)
 }  // namespace
 
-static bool pg_pick_shape(PlaneGArgs& a, int TY, int TX, int s2d, int Cin) {
+static bool pg_pick_shape(PlaneGArgs& a, int TY, int TX, int s2d, int Cin, int N, bool want_mat) {
   const int HW = a.Ho * a.Wo;
   const int last = (a.Ho - 1 + TY - 1) * a.WP + (a.Wo - 1 + TX - 1);              // last raster position any tap reads
-  a.shape = -1; a.R = a.Ho; a.nbands = 1;
+  a.shape = -1; a.R = a.Ho; a.nbands = 1; a.gimg = 1; a.Hst = 1 << 20;
+  // several images per workgroup (see the kernel) for planes that fill less than half of the smallest tile: the largest power of two
+  // G <= 4 that divides N, fits the tile and its raster, and leaves at least 16 planes; never with a fused norm (its statistics are
+  // per image)
+  if (!s2d && !want_mat && !S2P_DIAG_SWITCH(20)) {
+    const int over = TY - 1 - a.PT > a.PT ? TY - 1 - a.PT : a.PT;                 // zero rows between two stacked images
+    for (int G = 4; G >= 2; G >>= 1) {
+      if (N % G || N / G < 16) continue;
+      const int Hst = a.Hs + over, lastg = ((G - 1) * Hst + a.Ho - 1 + TY - 1) * a.WP + (a.Wo - 1 + TX - 1);
+      for (int i = 0; i < (int)(sizeof(PG_SHAPES) / sizeof(PG_SHAPES[0])); ++i) {
+        const PgShape& sh = PG_SHAPES[i];
+        if (i == PG_BAND_SHAPE_SHORTK || sh.TY != TY || sh.TX != TX || sh.S2D != s2d) continue;
+        if (2 * HW > 4 * sh.PB * 16) break;                                          // one image already fills half of this tile
+        if (G * HW <= 4 * sh.PB * 16 && lastg < sh.NPB) { a.shape = i; a.gimg = G; a.Hst = Hst; return true; }
+        break;                                                                      // (only the smallest tile of the tap rectangle)
+      }
+    }
+  }
   for (int i = 0; i < (int)(sizeof(PG_SHAPES) / sizeof(PG_SHAPES[0])); ++i) {     // (ordered by tile size: the smallest that fits)
     const PgShape& s = PG_SHAPES[i];
     if (i != PG_BAND_SHAPE_SHORTK && s.TY == TY && s.TX == TX && s.S2D == s2d && HW <= 4 * s.PB * 16 && last < s.NPB) { a.shape = i; break; }
@@ -641,7 +665,7 @@ bool s2p_conv_planeg_setup(const PlaneGProblem& p, PlaneGArgs& a) {
     a.PT = 1; a.PL = 1;
     const int PR = p.Wo - a.Ws > 0 ? p.Wo - a.Ws : 0;
     a.WP = a.Ws + (PR > 1 ? PR : 1);
-    return pg_pick_shape(a, 2, 2, 1, p.Cin);
+    return pg_pick_shape(a, 2, 2, 1, p.Cin, p.N, p.want_mat);
   }
   if (p.istride != 1) return false;
   if (p.T < 1 || p.T > 16) return false;
@@ -665,7 +689,7 @@ bool s2p_conv_planeg_setup(const PlaneGProblem& p, PlaneGArgs& a) {
   // overhang) zero columns, which serve as the right pad of a row AND the left pad of the next one
   const int PR = p.Wo - p.Wi + dx1 > 0 ? p.Wo - p.Wi + dx1 : 0;
   a.WP = p.Wi + (a.PL > PR ? a.PL : PR);
-  return pg_pick_shape(a, TY, TX, 0, p.Cin);
+  return pg_pick_shape(a, TY, TX, 0, p.Cin, p.N, p.want_mat);
 }
 
 template <int TY, int TX, int PB, int NPB, bool S2D>
@@ -681,7 +705,8 @@ int s2p_conv_planeg_launch(PlaneGArgs& a, int groups, hipStream_t st) {
   a.img_xcd = (a.N % 8 == 0 && a.nbands > 1 && !S2P_DIAG_SWITCH(15)) ? 1 : 0;      // all bands of an image on one XCD (see the kernel)
   if (a.gb) S2P_FAIL(-1, "conv_planeg: gamma / beta maps are not instantiated for this kernel family");
   if (a.nbands > 1 && a.y2) S2P_FAIL(-1, "conv_planeg: the fused norm needs the whole plane in one workgroup");
-  dim3 grid(a.N * a.nbands * a.nco, groups);
+  if (a.gimg > 1 && (a.y2 || a.nbands > 1 || a.N % a.gimg)) S2P_FAIL(-1, "conv_planeg: several images per plane exclude the fused norm and row bands");
+  dim3 grid((a.N / a.gimg) * a.nbands * a.nco, groups);
   if (a.shape == 0) pg_launch_shape<4, 4, 1, 128, false>(a, grid, st);
   else if (a.shape == 1) pg_launch_shape<4, 4, 3, 256, false>(a, grid, st);
   else if (a.shape == 2) pg_launch_shape<2, 2, 1, 128, true>(a, grid, st);

@@ -1020,7 +1020,7 @@ extern "C" __attribute__((visibility("default"))) int s2p_diag_vgpr_canary(int b
 // 11 = 64-channel slabs for the 42x42 InstanceNorm forward, 12 = the round-2 logit-head weight gradient, 15 = row bands dealt round-robin
 // over the XCDs, 16 = one (not two) workgroups per CU as the K-split target of the 4x4 weight gradients, 17 = the PAIR launch's group in
 // blockIdx.y, 18 = the slab weight gradients' (n, row, column) address state instead of the tabulated padded raster, 19 = the same for
-// the implicit-GEMM weight gradient's gathered operand (wgrad_dma_kernel)
+// the implicit-GEMM weight gradient's gathered operand (wgrad_dma_kernel), 20 = one image per plane in conv_planeg (no stacked planes)
 int s2p_diag_switch[32] = {0};
 extern "C" __attribute__((visibility("default"))) int s2p_diag_set(int key, int value) {
   if (key < 0 || key >= 32) return -1;

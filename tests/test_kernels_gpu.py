@@ -953,15 +953,19 @@ def test_conv_planeg_4x4_stride1(hip_device, shape):
         assert rel_err(dxn.float().cpu(), dx2.float().cpu().double()) < 1e-2
 
 
-@pytest.mark.parametrize("shape", [(8, 512, 512, 10, 10), (3, 256, 512, 10, 10), (5, 64, 128, 9, 11), (64, 512, 512, 10, 10)])
+@pytest.mark.parametrize("shape", [(8, 512, 512, 10, 10), (3, 256, 512, 10, 10), (5, 64, 128, 9, 11), (64, 512, 512, 10, 10),
+                                   (64, 512, 512, 5, 5),      # VGG conv5_1 at the production batch: FOUR images stacked in one plane
+                                   (32, 64, 128, 6, 4),       # two images per plane (N / 4 < 16 planes), ragged 6 x 4
+                                   (64, 128, 64, 3, 7)])      # four images of 21 pixels, wider than tall
 def test_conv_planeg_3x3_small_planes(hip_device, shape):
     """3x3 stride-1 pad-1 convs on planes of 65..128 pixels (VGG conv4_x at 10x10; 9x11 ragged) on the generalised plane-resident
     kernel (csrc/conv_planeg.hip): forward with bias + ReLU, and the dgrad with the fused producer-activation gradient and a second
-    incoming gradient (the VGG taps), against float64."""
+    incoming gradient (the VGG taps), against float64.  Planes of fewer than 64 pixels (round 5): 2 or 4 consecutive images share a
+    workgroup, stacked in one padded raster with a common zero row between them -- every image of the batch is compared."""
     dev = hip_device
     dtype = torch.bfloat16
     N, cin, cout, H, W = shape
-    pick = list(range(N)) if N <= 8 else [0, 21, 42, 63]
+    pick = list(range(N)) if (N <= 8 or H * W < 64) else [0, 21, 42, 63]
     g = torch.Generator().manual_seed(31)
     r = lambda *sh: torch.randn(*sh, generator=g).bfloat16().float()      # noqa: E731
     x, w, b = r(N, cin, H, W), r(cout, cin, 3, 3) / math.sqrt(cin * 9), torch.randn(cout, generator=g)
