@@ -29,7 +29,7 @@ extern "C" {
 /* the library is built with -fvisibility=hidden: only the entry points declared here are exported */
 #pragma GCC visibility push(default)
 
-#define S2P_VERSION 123
+#define S2P_VERSION 124
 
 enum { S2P_F32 = 0, S2P_BF16 = 1 };
 enum { S2P_ACT_NONE = 0, S2P_ACT_RELU = 1, S2P_ACT_LRELU = 2, S2P_ACT_TANH = 3, S2P_ACT_SWISH = 4 };
@@ -105,7 +105,9 @@ int s2p_conv2d_dgrad_ws(const s2p_conv_desc* d, const void* dy, const void* w_bw
  * launch: the workgroup that owns an (image, 64-channel) plane of y normalises it in its epilogue (csrc/conv_plane.hip);
  * so is it, without gamma / beta maps (plain InstanceNorm: gb_img == NULL), for the PatchGAN 4x4 stride-1 layers on planes
  * of up to 192 pixels (csrc/conv_planeg.hip).  Other shapes run the two calls above back to back
- * (s2p_conv2d_mat_is_fused tells which).  groups must be 1; act: none / relu / lrelu.                                 */
+ * (s2p_conv2d_mat_is_fused tells which).  groups must be 1; act: none / relu / lrelu.
+ * y may be NULL where the launch is fused (s2p_conv2d_mat_is_fused): the conv output itself is then not written -- a forward
+ * pass that keeps nothing for a backward only needs y_mat.                                                               */
 int s2p_conv2d_fwd_mat(const s2p_conv_desc* d, const void* x, const void* w_fwd, const float* bias, const void* aux,
                        void* y, int epi, const void* gb_img, int gb_pitch, const float* gb_st, int gb_st_pitch,
                        int act, float slope, float eps, void* y_mat, int y_mat_pitch, float* stats, void* workspace,

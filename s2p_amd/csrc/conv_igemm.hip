@@ -1567,7 +1567,7 @@ static int conv_fwd_impl(const s2p_conv_desc* d, const void* x, const void* w_fw
   S2P_CHECK_SLOPE("s2p_conv2d_fwd", act, slope);
   if (sc.mat) S2P_CHECK_SLOPE("s2p_conv2d_fwd_mat", sc.mat->act, sc.mat->slope);
   if (!sc.plan) {
-    if (!x || !w_fwd || !y) S2P_FAIL(-1, "s2p_conv2d_fwd: null pointer");
+    if (!x || !w_fwd || (!y && !sc.mat)) S2P_FAIL(-1, "s2p_conv2d_fwd: null pointer");      // (y == NULL: s2p_conv2d_fwd_mat checked that the launch is fused)
     if (epi != S2P_EPI_STORE && !aux) S2P_FAIL(-1, "s2p_conv2d_fwd: epi needs aux");
   }
   hipStream_t st = (hipStream_t)stream;
@@ -1606,13 +1606,18 @@ extern "C" int s2p_conv2d_fwd_mat(const s2p_conv_desc* d, const void* x, const v
                                   void* y, int epi, const void* gb_img, int gb_pitch, const float* gb_st, int gb_st_pitch,
                                   int act, float slope, float eps, void* y_mat, int y_mat_pitch, float* stats, void* workspace,
                                   size_t workspace_bytes, void* stream) {
-  if (!d || !y || !y_mat || !stats) S2P_FAIL(-1, "s2p_conv2d_fwd_mat: null pointer");
+  if (!d || !y_mat || !stats) S2P_FAIL(-1, "s2p_conv2d_fwd_mat: null pointer");
+  // y == NULL: the conv output itself is not wanted (a forward pass without a backward: it is written only for the backward's sake) --
+  // allowed where conv and norm are ONE launch, which then skips that store
+  if (!y && !s2p_conv2d_mat_is_fused(d, 0, gb_img != nullptr))
+    S2P_FAIL(-1, "s2p_conv2d_fwd_mat: y == NULL needs the fused launch (s2p_conv2d_mat_is_fused)");
   if (act != S2P_ACT_NONE && act != S2P_ACT_RELU && act != S2P_ACT_LRELU) S2P_FAIL(-1, "s2p_conv2d_fwd_mat: activation must be none / relu / lrelu");
   if (d->groups != 1 || d->transposed) S2P_FAIL(-1, "s2p_conv2d_fwd_mat: groups == 1, not transposed");
   PlaneMat m{y_mat, y_mat_pitch, gb_img, gb_pitch, gb_st, gb_st_pitch, stats, act, slope, eps, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0};
   int done = 0;
   int rc = conv_fwd_impl(d, x, w_fwd, bias, aux, y, S2P_ACT_NONE, 0.f, epi, Scratch{workspace, workspace_bytes, nullptr, &m, &done}, stream);
   if (rc || done) return rc;
+  if (!y) S2P_FAIL(-1, "s2p_conv2d_fwd_mat: y == NULL but the launch was not fused");
   // shapes the plane-resident kernel does not take: the conv above + the norm as its own launch(es)
   return s2p_in_norm_fwd(d->dtype, y, d->N, d->Ho * d->Wo, d->Cout, d->y_pitch, gb_img, gb_pitch, gb_st, gb_st_pitch, act, slope,
                          eps, y_mat, y_mat_pitch, stats, stream);

@@ -529,7 +529,7 @@ __global__ __launch_bounds__(512) void conv_plane_kernel(const PlaneArgs a) {
       if (row < HW) {
         const size_t go = ((size_t)img * HW + row) * a.y_pitch + co_base + ch * 8;
         if constexpr (GST != 0) xv[k] = out_chunk(row, ch, go, &pre_a[k]); else xv[k] = out_chunk(row, ch, go);
-        *(u32x4*)(yg + go) = xv[k].raw;
+        if (a.y) *(u32x4*)(yg + go) = xv[k].raw;                  // (y == NULL: the caller keeps only the modulated tensor -- a forward without a backward)
       }
       xv[k].unpack(xf[k]);                                        // rows beyond HW hold zeros
     }

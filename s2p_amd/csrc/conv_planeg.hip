@@ -385,7 +385,7 @@ __global__ __launch_bounds__(512, ((PB <= 3 && (TY == 3 || PG_OCC4_ALL)) ? 4 : 2
       if (row < HW) {
         const size_t go = (pix0 + row) * a.y_pitch + co_base + ch * 8;
         xv[k] = out_chunk(row, ch, go);
-        *(u32x4*)(yg + go) = xv[k].raw;
+        if (a.y) *(u32x4*)(yg + go) = xv[k].raw;                  // (y == NULL: only the normalised tensor is wanted)
       }
     }
     // the plane unpacked ONCE, the centred values kept from the second pass for the third (conv_plane.hip, MAT == 1; round 5)

@@ -313,7 +313,8 @@ class S2PGenerator(BaseNetwork):
                 # (s2p_conv2d_fwd_mat): conv_0 -> norm_1, and conv_1 + skip -> norm_0 of the NEXT block
                 if nA is None:
                     nA, sA = ops.in_norm_fwd(x, C, *G0, st_all, o0, ACT_LRELU, LRELU)
-                c0, nB, sB = L[f"b{b}c0"].fwd_mat(nA, *G1, st_all, o1, ACT_LRELU, LRELU)
+                # (conv_0's own output is only the backward's input: a forward that saves nothing does not write it)
+                c0, nB, sB = L[f"b{b}c0"].fwd_mat(nA, *G1, st_all, o1, ACT_LRELU, LRELU, want_y=save)
                 blocks.append((x, sA, nA, c0, sB, nB))
                 if b + 1 < self.n_blocks:
                     o0n = (2 * b + 2) * 2 * C

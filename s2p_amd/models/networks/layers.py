@@ -53,10 +53,11 @@ class ConvLayer:
                      x_off=g0 * gm.x_gstride)
         return out5
 
-    def fwd_mat(self, x, gb, gb_off, gb_st, st_off, act, slope, aux=None, epi=EPI_STORE):
-        """conv (+ residual) -> InstanceNorm -> MAT modulation -> activation; returns (conv output, modulated, stats)."""
+    def fwd_mat(self, x, gb, gb_off, gb_st, st_off, act, slope, aux=None, epi=EPI_STORE, want_y=True):
+        """conv (+ residual) -> InstanceNorm -> MAT modulation -> activation; returns (conv output, modulated, stats).
+        want_y=False: the conv output is only kept for a backward pass -- a fused launch then does not write it (returns None)."""
         return ops.conv_fwd_mat(self.geom, x, self.pk.w_fwd, self.pk.bias, self.cin_pad(x.dtype), gb, gb_off, gb_st, st_off,
-                                act=act, slope=slope, aux=aux, epi=epi)
+                                act=act, slope=slope, aux=aux, epi=epi, want_y=want_y)
 
     def dgrad(self, dy, x_shape, aux=None, epi=EPI_STORE, aux_act=ACT_NONE, slope=0.2, aux2=None):
         if dy.dim() == 5:           # group-major dy ([groups, N, Ho, Wo, pitch]: see fwd_group_major)

@@ -114,18 +114,30 @@ def conv_fwd(geom, x, w_fwd, bias, cin_pad, y_pitch=None, act=ACT_NONE, slope=0.
     return y
 
 
-def conv_fwd_mat(geom, x, w_fwd, bias, cin_pad, gb, gb_off, gb_st, st_off, act=ACT_LRELU, slope=0.2, aux=None, epi=EPI_STORE):
+def conv_fwd_mat(geom, x, w_fwd, bias, cin_pad, gb, gb_off, gb_st, st_off, act=ACT_LRELU, slope=0.2, aux=None, epi=EPI_STORE,
+                 want_y=True):
     """conv (+ bias, + residual aux) followed by InstanceNorm + MAT modulation + activation of its output, one launch where
     the plane-resident kernel applies (s2p_conv2d_fwd_mat; conv_fwd + in_norm_fwd otherwise).
-    Returns (y, y_mat, stats): the conv output (kept for the backward), the modulated activation, the norm statistics."""
+    Returns (y, y_mat, stats): the conv output (kept for the backward), the modulated activation, the norm statistics.
+    want_y=False (a forward without a backward): where the launch is fused the conv output is not written at all (y is None)."""
     N, H, W, xp = x.shape
     Ho, Wo = geom.out_hw(H, W)
     C = geom.cout
     y_pitch = pad_to(C, chunk_elems(x.dtype))
-    y = torch.empty((N, Ho, Wo, y_pitch), dtype=x.dtype, device=x.device)
     y_mat = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
     stats = torch.empty(lib().s2p_in_stats_floats(N, Ho * Wo, C), dtype=torch.float32, device=x.device)
     d = geom.desc(x.dtype, N, H, W, cin_pad, xp, y_pitch)
+    y = None
+    if not want_y:
+        # (the answer is a property of the geometry: asked once -- the query walks the launcher's planning path on the host, which an
+        # eager forward cannot afford six times per pass)
+        fc = geom.__dict__.setdefault("_mat_fused", {})
+        key = (x.dtype, N, H, W, cin_pad, xp, gb is not None)
+        if key not in fc:
+            fc[key] = bool(lib().s2p_conv2d_mat_is_fused(ctypes.byref(d), 0, 1 if gb is not None else 0))
+        want_y = not fc[key]
+    if want_y:
+        y = torch.empty((N, Ho, Wo, y_pitch), dtype=x.dtype, device=x.device)
     need = lib().s2p_conv2d_fwd_workspace(ctypes.byref(d), epi)
     ws = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None
     gbp, gb_pitch, stp, st_pitch = _gb_args(gb, gb_off, gb_st, st_off)

@@ -776,6 +776,13 @@ def test_conv_fwd_mat_fused(hip_device, dtype, shape, residual):
     dx2 = ops.in_bwd(dad, y, cout, stats2, gbd, 16, std, 8, ACT_LRELU, 0.2, torch.empty_like(gbd), 16, torch.empty_like(std), 8)
     torch.cuda.synchronize()
     assert rel_err(dx1.float().cpu(), dx2.float().cpu().double()) < (1e-5 if dtype == torch.float32 else 6e-3)
+    # a forward that keeps nothing for a backward: where the launch is fused the conv output is not written (y is None), the
+    # modulated tensor and the statistics are the same bits
+    y0, ym0, stats0 = ops.conv_fwd_mat(geom, xd, wf, b.to(dev), cin, gbd, 16, std, 8, act=ACT_LRELU, slope=0.2,
+                                       aux=xd if residual else None, epi=EPI_ADD if residual else EPI_STORE, want_y=False)
+    nst = 4 + N * cout * 2                                   # header + [N][C]{mean, M2} of a one-split statistics buffer (the rest is never written)
+    assert torch.equal(ym0, ym) and torch.equal(stats0[:nst], stats[:nst])
+    assert (y0 is None) or torch.equal(y0, y)
 
 
 @pytest.mark.parametrize("dtype,shape", [
