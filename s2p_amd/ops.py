@@ -69,6 +69,10 @@ def pad_to(c, ce):
     return (c + ce - 1) // ce * ce
 
 
+_MAT_FUSED = {}           # (geometry, problem) -> s2p_conv2d_mat_is_fused, asked once (conv_fwd_mat)
+SKIP_UNUSED_Y = True      # conv_fwd_mat(want_y=False) really skips the conv output (tools/ab_step.py flips it for same-box A/Bs)
+
+
 class ConvGeom:
     """Static geometry of one conv layer (F.conv2d / F.conv_transpose2d arguments)."""
 
@@ -128,14 +132,18 @@ def conv_fwd_mat(geom, x, w_fwd, bias, cin_pad, gb, gb_off, gb_st, st_off, act=A
     stats = torch.empty(lib().s2p_in_stats_floats(N, Ho * Wo, C), dtype=torch.float32, device=x.device)
     d = geom.desc(x.dtype, N, H, W, cin_pad, xp, y_pitch)
     y = None
+    if not SKIP_UNUSED_Y:
+        want_y = True
     if not want_y:
         # (the answer is a property of the geometry: asked once -- the query walks the launcher's planning path on the host, which an
         # eager forward cannot afford six times per pass)
-        fc = geom.__dict__.setdefault("_mat_fused", {})
-        key = (x.dtype, N, H, W, cin_pad, xp, gb is not None)
-        if key not in fc:
-            fc[key] = bool(lib().s2p_conv2d_mat_is_fused(ctypes.byref(d), 0, 1 if gb is not None else 0))
-        want_y = not fc[key]
+        # (a module-level table: layers compare their geometry objects attribute by attribute -- ConvLayer.wgrad_many -- so nothing
+        # may be cached ON them)
+        key = (geom.cin, geom.cout, geom.k, geom.stride, geom.pad, geom.transposed, geom.reflect, geom.groups, geom.output_padding,
+               x.dtype, N, H, W, cin_pad, xp, gb is not None)
+        if key not in _MAT_FUSED:
+            _MAT_FUSED[key] = bool(lib().s2p_conv2d_mat_is_fused(ctypes.byref(d), 0, 1 if gb is not None else 0))
+        want_y = not _MAT_FUSED[key]
     if want_y:
         y = torch.empty((N, Ho, Wo, y_pitch), dtype=x.dtype, device=x.device)
     need = lib().s2p_conv2d_fwd_workspace(ctypes.byref(d), epi)

@@ -522,6 +522,46 @@ def test_dstep_reuses_the_gstep_real_pass(hip_device, tmp_path):
     assert _dreal_key(model, data["prev_image"], data["image"]) != key_before
 
 
+def test_resblk_weight_gradients_stay_batched_across_steps(hip_device, tmp_path, monkeypatch):
+    """The twelve ResBlk convs share one geometry, and ConvLayer.wgrad_many hands their weight gradients to ONE batched slab launch per
+    deferred batch only while their geometry objects compare equal attribute by attribute.  Round 5 once cached a per-layer query
+    result ON the geometry during the D step's no-grad generator forward: from the second step on the twelve layers fell back to
+    one implicit-GEMM launch each (+0.63 ms per step, found in the per-dispatch profile).  Two full G + D steps, every call counted."""
+    from s2p_amd import ops
+    opt, model, spec, pg, pd, pv = build("bf16", tmp_path)
+    prev, state, real = make_inputs(2, 84, 84, 17, seed=9)
+    data = dict(prev_image=prev.cuda(), state=state.cuda(), image=real.cuda())
+    calls = {"batched": [], "single": 0}
+    orig_b, orig_s = ops.conv_wgrad_batched, ops.conv_wgrad
+
+    def count_b(geom, jobs, *a, **k):
+        if geom.k == 3 and geom.cin == geom.cout and geom.stride == 1 and geom.groups == 1:
+            calls["batched"].append(len(jobs))
+        return orig_b(geom, jobs, *a, **k)
+
+    def count_s(geom, *a, **k):
+        if geom.k == 3 and geom.cin == geom.cout and geom.stride == 1 and geom.groups == 1:
+            calls["single"] += 1
+        return orig_s(geom, *a, **k)
+    monkeypatch.setattr(ops, "conv_wgrad_batched", count_b)
+    monkeypatch.setattr(ops, "conv_wgrad", count_s)
+    per_step = []
+    for _ in range(2):
+        calls["batched"].clear(); calls["single"] = 0
+        model.netG.store.zero_grad(); model.netD.store.zero_grad()
+        g_losses, _ = model(data, mode="generator")
+        sum(g_losses.values()).backward()
+        d_losses = model(data, mode="discriminator")            # (its generator forward runs without a backward: want_y = False)
+        sum(d_losses.values()).backward()
+        torch.cuda.synchronize()
+        per_step.append((sorted(calls["batched"]), calls["single"]))
+    n_blk = sum(1 for k in model.netG.lay if k.startswith("b") and k.endswith("c0"))
+    for batched, single in per_step:
+        assert single == 0, per_step                            # no ResBlk conv took the one-launch-per-layer path
+        assert sum(n for n in batched if n > 1) >= 2 * n_blk, per_step
+    assert per_step[0] == per_step[1], per_step
+
+
 def test_trainer_steps_and_checkpoint(hip_device, tmp_path):
     from s2p_amd.trainers.pix2pix_trainer import Pix2PixTrainer
     args = ["--env_type", "cheetah", "--batchSize", "2", "--precision", "bf16", "--gpu_ids", "0",
