@@ -900,12 +900,15 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const GatherArgs a) {
   const int wco0 = (wave / WPIX) * (TCO * 32);
   const int wpix0 = (wave % WPIX) * (TPIX * 32);
   unsigned long long vmask[TPIX];
+  const double hrcpQQ = s2p_rcp_f64(QQ), hrcpQw = s2p_rcp_f64(a.Qw);
 #pragma unroll
   for (int j = 0; j < TPIX; ++j) {
     int m = pix_base + wpix0 + 32 * j + r;
     unsigned long long mask = 0ull;
     if (m < a.M) {
-      int n = m / QQ, rr = m - n * QQ, qy = rr / a.Qw, qx = rr - qy * a.Qw;
+      int rr, qx;
+      const int n = divmod_rcp(m, QQ, hrcpQQ, rr), qy = divmod_rcp(rr, a.Qw, hrcpQw, qx);
+      (void)n;
       for (int t0 = 0; t0 < a.T; t0 += 8) {            // 8 tap words per round: the scalar loads go out back to back
         int tv[8];
 #pragma unroll

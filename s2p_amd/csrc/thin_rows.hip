@@ -556,7 +556,7 @@ __global__ __launch_bounds__(512) void thin4_fwd_kernel(const Thin4Args a) {    
         }
     };
     if (tanh_act) pack([](float t) { return tanhf(t); });
-    else pack([ns](float t) { return t > 0.f ? t : t * ns; });
+    else pack([ns](float t) { return lrelu_ns(t, ns); });
     // transpose through the wave's private strip (32 pixel rows of 128 + 16 bytes): 8 lanes per pixel, 8 pixels per store instruction.
     // DS operations of one wave execute in order: no wait between the passes.
     {
