@@ -2,7 +2,8 @@
 compared inside ONE process: capture A, time it, capture B, time it, alternating).  Usage:
     python tools/ab_step.py autograd_nodes.OVERLAP_VGG [rounds [valueA valueB]]      (values: Python literals, default True False)
     S2P_LIB=.../libs2p_hip_diag.so python tools/ab_step.py lib:0 3 0 1      (a run-time switch of the diagnostics library: s2p_diag_set(0, value))
-    S2P_LIB=.../libs2p_hip_diag.so python tools/ab_step.py env:S2P_WGRAD_BLOCKS 3 None 256   (an environment variable that library reads)"""
+    S2P_LIB=.../libs2p_hip_diag.so python tools/ab_step.py env:S2P_WGRAD_BLOCKS 3 None 256   (an environment variable that library reads)
+    python tools/ab_step.py tr:pipeline_d 3 False True          (an attribute of the trainer)"""
 import os, sys, time, importlib
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 sys.path.insert(1, os.path.join(R, "tools")); import uselib  # noqa: E402  (S2P_LIB=<second build> for an A/B)
@@ -23,6 +24,11 @@ if target.startswith("lib:"):
         def __setattr__(self, k, v):
             assert ctypes.CDLL(_lib._SO).s2p_diag_set(int(k[1:]), int(v)) == 0
     mod, attr = _LibSwitch(), "k" + target[4:]
+elif target.startswith("tr:"):             # an attribute of the trainer object (e.g. tr:pipeline_d), bound once the trainer exists
+    class _Tr:
+        def __setattr__(self, k, v):
+            setattr(tr, k, v)
+    mod, attr = _Tr(), target[3:]
 elif target.startswith("env:"):            # an environment variable the DIAGNOSTICS library reads at every call (None: unset)
     class _Env:
         def __setattr__(self, k, v):
